@@ -1,0 +1,246 @@
+/*
+ * rwr_hip.h — C ABI of the MI355X-native ray/path tracer (librwr_hip.so).
+ *
+ * This is the drop-in boundary for the reference's hot path
+ * (clejacquet/rust-wgpu-raytracing): everything `State::render` hands to its
+ * three WGSL compute passes through wgpu bind groups crosses this ABI as plain
+ * pointers and sizes instead.  The reference has no FFI of its own; each entry
+ * point below cites the reference interface it replaces (paths relative to
+ * /root/reference/).  The Rust binding a maintainer would add is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns RWR_OK (0) or a negative rwr_status; the message
+ *     for the calling thread's last failure is rwr_last_error_string().
+ *     Nothing aborts or panics (the reference unwrap()s: lib.rs:275,284,303,566).
+ *   - one context = one GPU = one caller thread (the reference's State is !Send,
+ *     lib.rs:256).  Rendering is asynchronous on the context's HIP stream;
+ *     rwr_readback()/rwr_synchronize() wait for it.
+ *   - caller owns host arrays; uploads copy; the context owns device memory
+ *     until rwr_ctx_destroy().
+ *   - all PODs are layout-identical to the reference's #[repr(C)] structs.
+ *   - framebuffer row 0 is the BOTTOM image row (y_nds grows with the row
+ *     index, compute.wgsl:152; the reference's blit compensates, lib.rs:39-64).
+ */
+#ifndef RWR_HIP_H
+#define RWR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define RWR_API __attribute__((visibility("default")))
+#else
+#define RWR_API
+#endif
+
+typedef enum rwr_status {
+    RWR_OK = 0,
+    RWR_ERR_INVALID_ARGUMENT = -1,
+    RWR_ERR_HIP = -2,            /* a HIP runtime call failed (no device, OOM, launch failure) */
+    RWR_ERR_NOT_READY = -3,      /* render before resize / scene upload */
+    RWR_ERR_IO = -4,             /* loader: file missing / unreadable   (anyhow::Error in resources.rs) */
+    RWR_ERR_PARSE = -5,          /* loader: malformed OBJ/MTL/PNG/JPEG */
+    RWR_ERR_UNSUPPORTED = -6
+} rwr_status;
+
+/* ------------------------------------------------------------------ PODs -- */
+
+/* CameraInvUniform, src/lib.rs:86-93 — binding g0 b3 (compute.wgsl:10-14,57-58).
+ * Matrices are column-major: m[col][row] (cgmath `Into<[[f32;4];4]>`). */
+typedef struct rwr_camera_inv_uniform {
+    float viewmodel_inv[4][4];
+    float proj_inv[4][4];       /* = OPENGL_TO_WGPU_MATRIX * perspective^-1, lib.rs:109 */
+    float origin[3];
+    uint32_t _padding;
+} rwr_camera_inv_uniform;
+
+/* Screen, src/lib.rs:216-221 — binding g0 b4 (compute.wgsl:16-19,60-61). */
+typedef struct rwr_screen {
+    uint32_t width, height;
+} rwr_screen;
+
+/* ModelVertexSmall, src/model.rs:45-63 — binding g0 b5 element (compute.wgsl:27-30,63-64). */
+typedef struct rwr_model_vertex_small {
+    float position[3];
+    float pad0;
+    float tex_coords[2];
+    float pad1[2];
+} rwr_model_vertex_small;
+
+/* ModelFaceSmall, src/model.rs:65-79 — binding g0 b6 element (compute.wgsl:66-67). */
+typedef struct rwr_model_face_small {
+    uint32_t indices[3];
+    uint32_t pad0;
+} rwr_model_face_small;
+
+/* MaterialData, src/models/triangle_list/triangle_list.rs:24-33 — binding g0 b7 (compute.wgsl:32-36,69-70). */
+typedef struct rwr_material_data {
+    float ambient[3];  float pad0;
+    float diffuse[3];  float pad1;
+    float specular[3]; float pad2;
+} rwr_material_data;
+
+/* SphereBufferData, src/models/sphere/sphere.rs:10-15 — sphere binding g0 b5 (sphere/compute.wgsl:21-24,49-50). */
+typedef struct rwr_sphere_buffer_data {
+    float center[3];
+    float radius;
+} rwr_sphere_buffer_data;
+
+/* InstanceRaw, src/lib.rs:129-134 (computed but never bound by the reference;
+ * used here by the instanced configs).  Column-major model matrix; must be rigid
+ * (rotation + translation). */
+typedef struct rwr_instance_raw {
+    float model[4][4];
+} rwr_instance_raw;
+
+/* Camera, src/camera.rs:3-11 (cgmath Point3/Vector3 flattened). */
+typedef struct rwr_camera {
+    float eye[3];
+    float target[3];
+    float up[3];
+    float aspect;
+    float fovy;   /* degrees */
+    float znear;
+    float zfar;
+} rwr_camera;
+
+/* Extension (no reference counterpart): how many samples / bounces to trace. */
+typedef struct rwr_render_params {
+    uint32_t spp;          /* >= 1.  1 = the reference's single centre sample        */
+    uint32_t max_bounces;  /* 0 = reference (primary rays only); 1 = one diffuse bounce */
+    uint32_t seed;         /* RNG stream key; results do not depend on GPU count     */
+    uint32_t flags;        /* RWR_FLAG_*                                              */
+} rwr_render_params;
+
+enum {
+    RWR_FLAG_AUX_OUTPUTS = 1u << 0, /* also produce float colour, object id and hit distance planes */
+    RWR_FLAG_NO_CULL     = 1u << 1, /* debug: brute-force every face for every pixel (reference loop order) */
+    RWR_FLAG_USE_BVH     = 1u << 2  /* primary rays traverse the BVH instead of tile-frustum culling */
+};
+
+#define RWR_MAX_SPHERES 8
+
+/* Object id plane encoding (aux output): >= 0 mesh face index
+ * (instance * n_faces + face), -1 background, -2-k analytic sphere k. */
+
+typedef struct rwr_context rwr_context;
+
+/* ------------------------------------------------------ context / device -- */
+
+/* Replaces wgpu Instance/Adapter/Device/Queue creation, src/lib.rs:266-303. */
+RWR_API int rwr_ctx_create(int device_id, rwr_context **out_ctx);
+RWR_API void rwr_ctx_destroy(rwr_context *ctx);
+RWR_API const char *rwr_last_error_string(void);
+RWR_API int rwr_device_count(int *out_count);
+/* Name, CU count and wavefront size of the context's device. */
+RWR_API int rwr_ctx_device_info(rwr_context *ctx, char *name, size_t name_cap, int *cu_count, int *wave_size);
+
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of
+ * the context's own stream.  NULL restores the context's stream. */
+RWR_API int rwr_ctx_set_stream(rwr_context *ctx, void *hip_stream);
+RWR_API void *rwr_ctx_get_stream(rwr_context *ctx);
+
+/* ---------------------------------------------------------------- scene -- */
+
+/* Replaces the storage/uniform/texture bindings TriangleList feeds the mesh pass:
+ * vertice_list, face_list, material, texture_diffuse + sampler
+ * (src/lib.rs:617-669, triangle_list.rs:212-250, resources.rs:189-203,215-261).
+ * `rgba8_srgb` is tex_w*tex_h RGBA8 texels, row 0 = first row of the image
+ * file, interpreted as Rgba8UnormSrgb with a ClampToEdge / linear-mag sampler
+ * (texture.rs:122,151-159).  n_faces may be 0 (spheres only). */
+RWR_API int rwr_scene_upload_mesh(rwr_context *ctx,
+                                  const rwr_model_vertex_small *verts, uint32_t n_verts,
+                                  const rwr_model_face_small *faces, uint32_t n_faces,
+                                  const rwr_material_data *material,
+                                  const uint8_t *rgba8_srgb, uint32_t tex_w, uint32_t tex_h);
+
+/* Replaces Sphere::new's uniform, one per analytic sphere pass, composited in
+ * array order before the mesh (src/lib.rs:532-534, 1106-1173).  n <= RWR_MAX_SPHERES. */
+RWR_API int rwr_scene_set_spheres(rwr_context *ctx, const rwr_sphere_buffer_data *spheres, uint32_t n);
+
+/* Extension: rigid instances of the uploaded mesh (InstanceRaw layout).
+ * n = 0 restores the single un-instanced mesh of the reference. */
+RWR_API int rwr_scene_set_instances(rwr_context *ctx, const rwr_instance_raw *instances, uint32_t n);
+
+/* ---------------------------------------------------------------- frame -- */
+
+/* Replaces State::resize's target (re)creation: screen_texture (rgba8unorm),
+ * depth_texture_input/output (r32float) — src/lib.rs:470-515, 772-860. */
+RWR_API int rwr_resize(rwr_context *ctx, const rwr_screen *screen);
+
+/* Replaces State::render's GPU work, src/lib.rs:1024-1184: clear, sphere passes,
+ * depth copies and the mesh pass, as ONE fused launch when params are the
+ * reference's (spp 1, no bounce); the wavefront integrator otherwise.
+ * Asynchronous.  `params` may be NULL (= {1,0,0,0}). */
+RWR_API int rwr_render(rwr_context *ctx, const rwr_camera_inv_uniform *camera, const rwr_render_params *params);
+
+/* Same, restricted to framebuffer rows [row_begin,row_end): the band one rank
+ * renders when a frame is split across GPUs.  Pixels are addressed and the RNG
+ * is keyed by GLOBAL pixel coordinates, so bands assemble bit-identically. */
+RWR_API int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera,
+                            const rwr_render_params *params, uint32_t row_begin, uint32_t row_end);
+
+RWR_API int rwr_synchronize(rwr_context *ctx);
+
+/* Copies finished targets to host memory (synchronises first).  Any pointer may
+ * be NULL.  rgba8: W*H*4 bytes (screen_texture); depth: W*H floats
+ * (depth_texture_output); the last three need RWR_FLAG_AUX_OUTPUTS on the render. */
+RWR_API int rwr_readback(rwr_context *ctx, uint8_t *rgba8, float *depth,
+                         float *rgba_f32, int32_t *obj_id, float *hit_t);
+
+/* Device addresses of the targets, for zero-copy consumers (RCCL gather of
+ * finished bands, presentation).  Valid until the next rwr_resize. */
+RWR_API int rwr_get_device_targets(rwr_context *ctx, void **d_rgba8, void **d_depth);
+
+/* hipEvent timing on the stream the kernels are launched on. */
+RWR_API int rwr_timer_begin(rwr_context *ctx);
+RWR_API int rwr_timer_end(rwr_context *ctx, float *elapsed_ms); /* synchronises on the end event */
+
+/* Segments (rays) traced by the last render call, for Mray/s accounting:
+ * W*rows*spp primary + bounce rays actually emitted. */
+RWR_API int rwr_last_render_stats(rwr_context *ctx, uint64_t *primary_rays, uint64_t *bounce_rays);
+
+/* ---------------------------------------------- host-side L2 surface (CPU) -- */
+
+/* CameraInvUniform::update_view_proj, src/lib.rs:105-111 with camera.rs:20-30. */
+RWR_API int rwr_camera_build_inv_uniform(const rwr_camera *camera, rwr_camera_inv_uniform *out);
+
+/* CircleCameraController::update_camera, src/circle_camera_control.rs:76-105. */
+enum { RWR_KEY_FORWARD = 1, RWR_KEY_BACKWARD = 2, RWR_KEY_LEFT = 4, RWR_KEY_RIGHT = 8,
+       RWR_KEY_UP = 16, RWR_KEY_DOWN = 32 };
+RWR_API int rwr_circle_controller_update(float speed, uint32_t pressed_keys, rwr_camera *camera);
+
+/* resources::load_model_compute, src/resources.rs:163-264: OBJ + MTL + diffuse
+ * texture from `res_dir`.  Only meshes[0]/materials[0] are exposed, as in
+ * TriangleList (triangle_list.rs:212-245). */
+typedef struct rwr_model rwr_model;
+RWR_API int rwr_load_model_compute(const char *res_dir, const char *file_name, rwr_model **out_model);
+RWR_API void rwr_model_free(rwr_model *model);
+RWR_API int rwr_model_info(const rwr_model *model, uint32_t *n_meshes, uint32_t *n_materials,
+                           uint32_t *n_verts, uint32_t *n_faces, uint32_t *tex_w, uint32_t *tex_h);
+RWR_API const rwr_model_vertex_small *rwr_model_vertices(const rwr_model *model);
+RWR_API const rwr_model_face_small *rwr_model_faces(const rwr_model *model);
+RWR_API const rwr_material_data *rwr_model_material(const rwr_model *model);
+RWR_API const uint8_t *rwr_model_texture_rgba8(const rwr_model *model);
+/* Convenience: rwr_scene_upload_mesh(ctx, <everything in model>). */
+RWR_API int rwr_scene_upload_model(rwr_context *ctx, const rwr_model *model);
+
+/* texture::Texture::from_bytes, src/texture.rs:98-106: decode PNG/JPEG bytes to
+ * RGBA8.  *out_rgba is malloc'd; free with rwr_free(). */
+RWR_API int rwr_decode_image_rgba8(const uint8_t *bytes, size_t n_bytes,
+                                   uint8_t **out_rgba, uint32_t *out_w, uint32_t *out_h);
+RWR_API void rwr_free(void *p);
+
+/* The grid of Instance{position,rotation}.to_raw() of src/lib.rs:400-421 for a
+ * given NUM_INSTANCES_PER_ROW / SPACE_BETWEEN; out must hold per_row*per_row. */
+RWR_API int rwr_make_instance_grid(uint32_t per_row, float space_between, rwr_instance_raw *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RWR_HIP_H */

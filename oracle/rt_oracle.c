@@ -1,0 +1,646 @@
+/*
+ * rt_oracle.c — CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A plain-C restatement of the reference renderer's per-pixel algorithm
+ * (clejacquet/rust-wgpu-raytracing).  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this; the product path
+ * (rust-wgpu-raytracing_amd/) never links, imports or calls it.
+ *
+ * PARITY UNPINNED: the reference holds no tests, golden images or known-answer
+ * vectors for this path and it cannot be built here (no
+ * Rust toolchain, no Vulkan ICD), so this restatement is pinned only by
+ *   (1) the analytic known answers in tests/test_oracle_kat.py and
+ *   (2) the provisional values SURVEY.md §8(c) recorded from an independent
+ *       float32 NumPy restatement.
+ * Third-party arithmetic that is not in /root/reference (cgmath 0.18.0
+ * look_at_rh / perspective / Matrix4::invert, naga/driver WGSL builtins) is
+ * restated from its published formulas.
+ *
+ * Reference lines followed (all relative to /root/reference/):
+ *   src/models/triangle_list/compute.wgsl:78-240   mesh pass
+ *   src/models/sphere/compute.wgsl:52-158          sphere pass
+ *   src/lib.rs:31-37, 86-112                       G = OPENGL_TO_WGPU, CameraInvUniform
+ *   src/camera.rs:13-30                            view/proj inverse builders
+ *   src/lib.rs:1024-1184                           frame sequence (clear, sphere, copy, sphere, copy, mesh)
+ *   src/circle_camera_control.rs:76-105            controller update
+ *   src/texture.rs:108-166                         Rgba8UnormSrgb + clamp/bilinear sampler
+ *
+ * ARITHMETIC SPEC (what "the same result" means, f32 everywhere):
+ *   WGSL leaves fusion and builtin precision to the implementation.  This
+ *   oracle fixes the LITERAL reading so that results are reproducible: every
+ *   expression is evaluated exactly as written, left to right, one IEEE-754
+ *   binary32 rounding per operation, NO fused multiply-add anywhere (build
+ *   with -ffp-contract=off), IEEE divide and sqrt, no fast-math:
+ *     dot(a,b)      = (a.x*b.x + a.y*b.y) + a.z*b.z
+ *     cross(a,b).x  = a.y*b.z - a.z*b.y                  (cyclic for y,z)
+ *     M*v (row i)   = ((m0i*v.x + m1i*v.y) + m2i*v.z) + m3i*v.w
+ *     o + t*d       = o + (t*d)  per component
+ *     normalize(v)  = v / sqrt(dot(v,v))
+ *   (An FMA-contracted reading is equally legal WGSL but opens cracks on
+ *   exactly symmetric shared edges, e.g. the cube's face diagonals seen from
+ *   the origin; the literal reading keeps edges inclusive as the shader
+ *   intends, compute.wgsl:118-138.)
+ *   pow(x,32) is libm powf.  sRGB decode uses a 256-entry f32 table built from
+ *   the double-precision transfer function.
+ *
+ * EXTENSIONS beyond the reference (BASELINE.json configs 3-5; defined by this
+ * project, see DESIGN.md §"Extended integrator"): sub-pixel jitter, spp > 1,
+ * one cosine-weighted diffuse bounce, rigid instances.  or_render_path().
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define OR_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ PODs -- */
+/* src/lib.rs:86-93 */
+typedef struct {
+    float viewmodel_inv[4][4]; /* column-major: [col][row] */
+    float proj_inv[4][4];
+    float origin[3];
+    uint32_t _padding;
+} OrCameraInvUniform;
+/* src/lib.rs:216-221 */
+typedef struct { uint32_t width, height; } OrScreen;
+/* src/model.rs:45-63 */
+typedef struct { float position[3]; float pad0; float tex_coords[2]; float pad1[2]; } OrVertex;
+/* src/model.rs:65-79 */
+typedef struct { uint32_t indices[3]; uint32_t pad0; } OrFace;
+/* src/models/triangle_list/triangle_list.rs:24-33 */
+typedef struct { float ambient[3]; float pad0; float diffuse[3]; float pad1; float specular[3]; float pad2; } OrMaterial;
+/* src/models/sphere/sphere.rs:10-15 */
+typedef struct { float center[3]; float radius; } OrSphere;
+/* src/camera.rs:3-11 */
+typedef struct { float eye[3]; float target[3]; float up[3]; float aspect, fovy, znear, zfar; } OrCamera;
+
+_Static_assert(sizeof(OrCameraInvUniform) == 144, "CameraInvUniform is 144 B");
+_Static_assert(sizeof(OrVertex) == 32, "ModelVertexSmall is 32 B");
+_Static_assert(sizeof(OrFace) == 16, "ModelFaceSmall is 16 B");
+_Static_assert(sizeof(OrMaterial) == 48, "MaterialData is 48 B");
+_Static_assert(sizeof(OrSphere) == 16, "SphereBufferData is 16 B");
+
+/* ------------------------------------------------------------- vec math -- */
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } v4;
+
+static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 v3_from(const float *p) { return V3(p[0], p[1], p[2]); }
+static inline v3 sub3(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 add3(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 neg3(v3 a) { return V3(-a.x, -a.y, -a.z); }
+static inline v3 scale3(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 cross3(v3 a, v3 b)
+{
+    return V3(a.y * b.z - a.z * b.y,
+              a.z * b.x - a.x * b.z,
+              a.x * b.y - a.y * b.x);
+}
+static inline v3 normalize3(v3 a)
+{
+    float len = sqrtf(dot3(a, a));
+    return V3(a.x / len, a.y / len, a.z / len);
+}
+static inline v3 madd3(float t, v3 d, v3 o) { return V3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z); }
+static inline v4 mat4_mul_v4(const float m[4][4], v4 v)
+{
+    v4 r;
+    r.x = m[0][0] * v.x + m[1][0] * v.y + m[2][0] * v.z + m[3][0] * v.w;
+    r.y = m[0][1] * v.x + m[1][1] * v.y + m[2][1] * v.z + m[3][1] * v.w;
+    r.z = m[0][2] * v.x + m[1][2] * v.y + m[2][2] * v.z + m[3][2] * v.w;
+    r.w = m[0][3] * v.x + m[1][3] * v.y + m[2][3] * v.z + m[3][3] * v.w;
+    return r;
+}
+
+/* ------------------------------------------------------- shader pieces -- */
+typedef struct { v3 origin, direction; } Ray;
+
+/* compute.wgsl:51-53 (both shaders) */
+static const float kNear = 0.01f;
+static const float kFar = 100.0f;
+static const float kEpsilon = 0.000001f;
+
+/* triangle_list/compute.wgsl:78-80, sphere/compute.wgsl:59-61 */
+static inline float to_non_linear_depth(float depth)
+{
+    return ((1.0f / depth) - (1.0f / kNear)) / ((1.0f / kFar) - (1.0f / kNear));
+}
+
+/* triangle_list/compute.wgsl:150-164 (sphere/compute.wgsl:87-101 is identical).
+ * (jx, jy) = (0.5, 0.5) in the reference; other values are the jitter extension. */
+static inline Ray pixel_to_ray(const OrCameraInvUniform *cam, const OrScreen *screen,
+                               uint32_t x, uint32_t y, float jx, float jy)
+{
+    float x_nds = 2.0f * ((float)x + jx) / (float)screen->width - 1.0f;
+    float y_nds = 2.0f * ((float)y + jy) / (float)screen->height - 1.0f;
+    v4 proj_vec = {x_nds, y_nds, 1.0f, 1.0f};
+    v4 view_vec = mat4_mul_v4(cam->proj_inv, proj_vec);
+    view_vec.w = 0.0f;
+    v4 world_vec = mat4_mul_v4(cam->viewmodel_inv, view_vec);
+    Ray r;
+    r.origin = v3_from(cam->origin);
+    r.direction = normalize3(V3(world_vec.x, world_vec.y, world_vec.z));
+    return r;
+}
+
+typedef struct {
+    int hit;
+    float distance;
+    v3 normal;
+    v3 barycentric;
+} HitRecord;
+
+static const HitRecord kNoHit = {0, 0.0f, {0, 0, 0}, {0, 0, 0}};
+
+/* triangle_list/compute.wgsl:82-148 */
+static inline HitRecord triangle_ray_intersect(v3 p0, v3 p1, v3 p2, Ray ray)
+{
+    v3 v0v1 = sub3(p1, p0);
+    v3 v0v2 = sub3(p2, p0);
+    v3 N = cross3(v0v1, v0v2);
+    float denom = dot3(N, N);
+
+    float NdotRayDirection = dot3(N, ray.direction);
+    if (fabsf(NdotRayDirection) < kEpsilon) return kNoHit;
+
+    float d = -dot3(N, p0);
+    float t = -(dot3(N, ray.origin) + d) / NdotRayDirection;
+    if (t < 0.0f) return kNoHit;
+
+    v3 P = madd3(t, ray.direction, ray.origin);
+
+    v3 edge0 = sub3(p1, p0);
+    v3 vp0 = sub3(P, p0);
+    v3 C = cross3(edge0, vp0);
+    if (dot3(N, C) < 0.0f) return kNoHit;
+
+    v3 edge1 = sub3(p2, p1);
+    v3 vp1 = sub3(P, p1);
+    C = cross3(edge1, vp1);
+    float u = dot3(N, C);
+    if (u < 0.0f) return kNoHit;
+
+    v3 edge2 = sub3(p0, p2);
+    v3 vp2 = sub3(P, p2);
+    C = cross3(edge2, vp2);
+    float v = dot3(N, C);
+    if (v < 0.0f) return kNoHit;
+
+    if (NdotRayDirection > 0.0f) N = neg3(N);
+
+    u = u / denom;
+    v = v / denom;
+
+    HitRecord h;
+    h.hit = 1;
+    h.distance = t;
+    h.normal = normalize3(N);
+    h.barycentric = V3(u, v, 1.0f - u - v);
+    return h;
+}
+
+/* sphere/compute.wgsl:52-85 */
+static inline HitRecord sphere_ray_intersect(v3 center, float radius, Ray ray)
+{
+    v3 oc = sub3(ray.origin, center);
+    float a = dot3(ray.direction, ray.direction);
+    float b = 2.0f * dot3(oc, ray.direction);
+    float c = dot3(oc, oc) - (radius * radius);
+    float discriminant = b * b - 4.0f * a * c;
+    if (discriminant < 0.0f) return kNoHit;
+    float sq = sqrtf(discriminant);
+    float t1 = (-b - sq) / (2.0f * a);
+    float t2 = (-b + sq) / (2.0f * a);
+    float t;
+    if (t1 >= 0.0f) t = t1;
+    else if (t2 >= 0.0f) t = t2;
+    else return kNoHit;
+    HitRecord h;
+    h.hit = 1;
+    h.distance = t;
+    v3 P = madd3(t, ray.direction, ray.origin); /* ray.origin + ray.direction * t */
+    h.normal = normalize3(sub3(P, center));
+    h.barycentric = V3(0, 0, 0);
+    return h;
+}
+
+/* texture.rs:122 (Rgba8UnormSrgb) — decode table, built once per call site. */
+static void build_srgb_lut(float lut[256])
+{
+    for (int i = 0; i < 256; i++) {
+        double c = (double)i / 255.0;
+        double l = (c <= 0.04045) ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4);
+        lut[i] = (float)l;
+    }
+}
+
+typedef struct {
+    const uint8_t *rgba; /* W*H*4, row 0 = first image row (top of the PNG) */
+    uint32_t w, h;
+    float lut[256];
+} Tex;
+
+/* textureSampleGrad(..., grad 0,0): LOD 0, magnification => bilinear,
+ * ClampToEdge, texels sRGB-decoded before filtering
+ * (triangle_list/compute.wgsl:225, texture.rs:151-159). */
+static inline v3 tex_sample_bilinear(const Tex *t, float u, float v)
+{
+    float fx = u * (float)t->w - 0.5f;
+    float fy = v * (float)t->h - 0.5f;
+    float x0f = floorf(fx), y0f = floorf(fy);
+    float ax = fx - x0f, ay = fy - y0f;
+    /* clamp in float first so that huge/NaN coordinates cannot overflow int */
+    float wmax = (float)(t->w - 1), hmax = (float)(t->h - 1);
+    float x0c = fminf(fmaxf(x0f, 0.0f), wmax), x1c = fminf(fmaxf(x0f + 1.0f, 0.0f), wmax);
+    float y0c = fminf(fmaxf(y0f, 0.0f), hmax), y1c = fminf(fmaxf(y0f + 1.0f, 0.0f), hmax);
+    uint32_t x0 = (uint32_t)x0c, x1 = (uint32_t)x1c, y0 = (uint32_t)y0c, y1 = (uint32_t)y1c;
+    const uint8_t *t00 = t->rgba + 4 * ((size_t)y0 * t->w + x0);
+    const uint8_t *t10 = t->rgba + 4 * ((size_t)y0 * t->w + x1);
+    const uint8_t *t01 = t->rgba + 4 * ((size_t)y1 * t->w + x0);
+    const uint8_t *t11 = t->rgba + 4 * ((size_t)y1 * t->w + x1);
+    float w00 = (1.0f - ax) * (1.0f - ay), w10 = ax * (1.0f - ay);
+    float w01 = (1.0f - ax) * ay, w11 = ax * ay;
+    float c[3];
+    for (int k = 0; k < 3; k++) {
+        c[k] = t->lut[t00[k]] * w00 + t->lut[t10[k]] * w10 + t->lut[t01[k]] * w01 + t->lut[t11[k]] * w11;
+    }
+    return V3(c[0], c[1], c[2]);
+}
+
+/* rgba8unorm store: clamp to [0,1], scale, round half up. */
+static inline uint8_t unorm8(float c)
+{
+    float cc = fminf(fmaxf(c, 0.0f), 1.0f);
+    return (uint8_t)floorf(cc * 255.0f + 0.5f);
+}
+
+/* ----------------------------------------------------------- the scene -- */
+typedef struct {
+    const OrVertex *verts; uint32_t n_verts;
+    const OrFace *faces;   uint32_t n_faces;
+    const OrMaterial *material;
+    Tex tex;
+} Mesh;
+
+/* Local shading of a mesh hit — triangle_list/compute.wgsl:217-234.
+ * Returns final_color.rgb (alpha is 2.0); *albedo receives the filtered texel
+ * (needed only by the bounce extension). */
+static inline v3 shade_mesh(const Mesh *m, uint32_t i_min, const HitRecord *h, Ray ray, v3 *albedo)
+{
+    const v3 kLightDir = {1.0f, -1.0f, -5.0f}; /* compute.wgsl:55 */
+    const OrFace *f = &m->faces[i_min];
+    const float *tc0 = m->verts[f->indices[0]].tex_coords;
+    const float *tc1 = m->verts[f->indices[1]].tex_coords;
+    const float *tc2 = m->verts[f->indices[2]].tex_coords;
+    float tu = h->barycentric.x * tc0[0] + h->barycentric.y * tc1[0] + h->barycentric.z * tc2[0];
+    float tv = h->barycentric.x * tc0[1] + h->barycentric.y * tc1[1] + h->barycentric.z * tc2[1];
+    tv = 1.0f - tv;
+    v3 tex = tex_sample_bilinear(&m->tex, tu, tv);
+    if (albedo) *albedo = tex;
+
+    v3 nl = neg3(normalize3(kLightDir));
+    float ndl = fmaxf(0.0f, dot3(h->normal, nl));
+    v3 diffuse = scale3(tex, ndl);
+    v3 half_dir = normalize3(sub3(nl, ray.direction));
+    float sp = powf(fmaxf(0.0f, dot3(half_dir, h->normal)), 32.0f);
+    v3 specular = V3(m->material->specular[0] * sp, m->material->specular[1] * sp, m->material->specular[2] * sp);
+    v3 out;
+    out.x = (m->material->ambient[0] + diffuse.x) + specular.x;
+    out.y = (m->material->ambient[1] + diffuse.y) + specular.y;
+    out.z = (m->material->ambient[2] + diffuse.z) + specular.z;
+    return out;
+}
+
+/* Local shading of a sphere hit — sphere/compute.wgsl:137-152. */
+static inline v3 shade_sphere(const HitRecord *h, Ray ray, v3 *albedo)
+{
+    const v3 kLightDir = {1.0f, -5.0f, 1.0f}; /* sphere/compute.wgsl:41 */
+    const float ambiant_comp = 0.1f, diffuse_comp = 1.0f, specular_comp = 0.5f;
+    v3 nl = neg3(normalize3(kLightDir));
+    float diffuse = diffuse_comp * fmaxf(0.0f, dot3(h->normal, nl));
+    v3 half_dir = normalize3(sub3(nl, ray.direction));
+    float specular = specular_comp * powf(fmaxf(0.0f, dot3(half_dir, h->normal)), 32.0f);
+    const v3 mat_color = {1.0f, 0.0f, 0.0f};
+    if (albedo) *albedo = mat_color;
+    float k = ambiant_comp + diffuse;
+    return V3(k * mat_color.x + specular, k * mat_color.y + specular, k * mat_color.z + specular);
+}
+
+/* Brute-force nearest hit, lowest index wins ties — compute.wgsl:186-202. */
+static inline HitRecord mesh_nearest(const Mesh *m, Ray ray, int *i_min_out)
+{
+    int i_min = 0;
+    HitRecord min_hit = kNoHit;
+    for (int i = 0; i < (int)m->n_faces; i++) {
+        const OrFace *f = &m->faces[i];
+        v3 p0 = v3_from(m->verts[f->indices[0]].position);
+        v3 p1 = v3_from(m->verts[f->indices[1]].position);
+        v3 p2 = v3_from(m->verts[f->indices[2]].position);
+        HitRecord hr = triangle_ray_intersect(p0, p1, p2, ray);
+        if ((!min_hit.hit && hr.hit) || (hr.hit && hr.distance < min_hit.distance)) {
+            min_hit = hr;
+            i_min = i;
+        }
+    }
+    *i_min_out = i_min;
+    return min_hit;
+}
+
+/* Output planes.  Any pointer may be NULL. */
+typedef struct {
+    uint8_t *color_u8;   /* W*H*4 rgba8unorm */
+    float *color_f32;    /* W*H*4 the vec4 handed to textureStore (pre-clamp) */
+    int32_t *obj_id;     /* W*H: face index >= 0 (instance*n_faces + face), -1 untouched, -2-k sphere k */
+    float *hit_t;        /* W*H: distance of the winning hit */
+} OrAux;
+
+static inline void store_pixel(const OrAux *o, size_t idx, v3 rgb, float alpha, int32_t id, float t)
+{
+    if (o->color_u8) {
+        o->color_u8[4 * idx + 0] = unorm8(rgb.x);
+        o->color_u8[4 * idx + 1] = unorm8(rgb.y);
+        o->color_u8[4 * idx + 2] = unorm8(rgb.z);
+        o->color_u8[4 * idx + 3] = unorm8(alpha);
+    }
+    if (o->color_f32) {
+        o->color_f32[4 * idx + 0] = rgb.x;
+        o->color_f32[4 * idx + 1] = rgb.y;
+        o->color_f32[4 * idx + 2] = rgb.z;
+        o->color_f32[4 * idx + 3] = alpha;
+    }
+    if (o->obj_id) o->obj_id[idx] = id;
+    if (o->hit_t) o->hit_t[idx] = t;
+}
+
+/* ------------------------------------------------ literal compute passes -- */
+/* sphere/compute.wgsl:114-158, one invocation per pixel. */
+OR_API void or_sphere_pass(const OrCameraInvUniform *cam, const OrScreen *screen, const OrSphere *sphere,
+                           int32_t sphere_index, const float *depth_input, float *depth_output,
+                           uint8_t *color_u8, float *color_f32, int32_t *obj_id, float *hit_t)
+{
+    OrAux aux = {color_u8, color_f32, obj_id, hit_t};
+    const int W = (int)screen->width, H = (int)screen->height;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            Ray ray = pixel_to_ray(cam, screen, (uint32_t)x, (uint32_t)y, 0.5f, 0.5f);
+            HitRecord h = sphere_ray_intersect(v3_from(sphere->center), sphere->radius, ray);
+            if (!h.hit) continue;
+            size_t idx = (size_t)y * W + x;
+            float current_depth = 1.0f - depth_input[idx];
+            float depth = to_non_linear_depth(h.distance);
+            if (depth >= current_depth) continue;
+            v3 rgb = shade_sphere(&h, ray, NULL);
+            depth_output[idx] = 1.0f - depth;
+            store_pixel(&aux, idx, rgb, 2.0f, -2 - sphere_index, h.distance);
+        }
+    }
+}
+
+/* triangle_list/compute.wgsl:177-240, one invocation per pixel. */
+OR_API void or_mesh_pass(const OrCameraInvUniform *cam, const OrScreen *screen,
+                         const OrVertex *verts, uint32_t n_verts, const OrFace *faces, uint32_t n_faces,
+                         const OrMaterial *material, const uint8_t *tex_rgba8, uint32_t tex_w, uint32_t tex_h,
+                         const float *depth_input, float *depth_output,
+                         uint8_t *color_u8, float *color_f32, int32_t *obj_id, float *hit_t)
+{
+    Mesh m;
+    m.verts = verts; m.n_verts = n_verts; m.faces = faces; m.n_faces = n_faces; m.material = material;
+    m.tex.rgba = tex_rgba8; m.tex.w = tex_w; m.tex.h = tex_h;
+    build_srgb_lut(m.tex.lut);
+    OrAux aux = {color_u8, color_f32, obj_id, hit_t};
+    const int W = (int)screen->width, H = (int)screen->height;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            Ray ray = pixel_to_ray(cam, screen, (uint32_t)x, (uint32_t)y, 0.5f, 0.5f);
+            int i_min;
+            HitRecord h = mesh_nearest(&m, ray, &i_min);
+            if (!h.hit) continue;
+            size_t idx = (size_t)y * W + x;
+            float current_depth = 1.0f - depth_input[idx];
+            float depth = to_non_linear_depth(h.distance);
+            if (depth >= current_depth) continue;
+            v3 rgb = shade_mesh(&m, (uint32_t)i_min, &h, ray, NULL);
+            depth_output[idx] = 1.0f - depth;
+            store_pixel(&aux, idx, rgb, 2.0f, i_min, h.distance);
+        }
+    }
+}
+
+/* State::render, src/lib.rs:1024-1184: clear screen/depth_in/depth_out to 0,
+ * then for each sphere {pass; copy depth_out -> depth_in}, then the mesh pass.
+ * Outputs: color_u8 (W*H*4), depth_out (W*H) and the optional aux planes.
+ * Returns 0, or -1 on allocation failure. */
+OR_API int or_render_frame(const OrCameraInvUniform *cam, const OrScreen *screen,
+                           const OrSphere *spheres, uint32_t n_spheres,
+                           const OrVertex *verts, uint32_t n_verts, const OrFace *faces, uint32_t n_faces,
+                           const OrMaterial *material, const uint8_t *tex_rgba8, uint32_t tex_w, uint32_t tex_h,
+                           uint8_t *color_u8, float *depth_out, float *color_f32, int32_t *obj_id, float *hit_t)
+{
+    size_t n = (size_t)screen->width * screen->height;
+    float *depth_in = (float *)calloc(n, sizeof(float));
+    if (!depth_in) return -1;
+    memset(depth_out, 0, n * sizeof(float));
+    if (color_u8) memset(color_u8, 0, n * 4);
+    if (color_f32) memset(color_f32, 0, n * 4 * sizeof(float));
+    if (obj_id) for (size_t i = 0; i < n; i++) obj_id[i] = -1;
+    if (hit_t) memset(hit_t, 0, n * sizeof(float));
+    for (uint32_t s = 0; s < n_spheres; s++) {
+        or_sphere_pass(cam, screen, &spheres[s], (int32_t)s, depth_in, depth_out, color_u8, color_f32, obj_id, hit_t);
+        memcpy(depth_in, depth_out, n * sizeof(float));
+    }
+    if (n_faces > 0)
+        or_mesh_pass(cam, screen, verts, n_verts, faces, n_faces, material, tex_rgba8, tex_w, tex_h,
+                     depth_in, depth_out, color_u8, color_f32, obj_id, hit_t);
+    free(depth_in);
+    return 0;
+}
+
+/* Single-ray probes used by the known-answer tests. */
+OR_API void or_pixel_to_ray(const OrCameraInvUniform *cam, const OrScreen *screen, uint32_t x, uint32_t y,
+                            float jx, float jy, float out_origin[3], float out_dir[3], float out_view_vec[4])
+{
+    Ray r = pixel_to_ray(cam, screen, x, y, jx, jy);
+    out_origin[0] = r.origin.x; out_origin[1] = r.origin.y; out_origin[2] = r.origin.z;
+    out_dir[0] = r.direction.x; out_dir[1] = r.direction.y; out_dir[2] = r.direction.z;
+    if (out_view_vec) {
+        float x_nds = 2.0f * ((float)x + jx) / (float)screen->width - 1.0f;
+        float y_nds = 2.0f * ((float)y + jy) / (float)screen->height - 1.0f;
+        v4 pv = {x_nds, y_nds, 1.0f, 1.0f};
+        v4 vv = mat4_mul_v4(cam->proj_inv, pv);
+        out_view_vec[0] = vv.x; out_view_vec[1] = vv.y; out_view_vec[2] = vv.z; out_view_vec[3] = vv.w;
+    }
+}
+
+OR_API int or_triangle_ray_intersect(const float p0[3], const float p1[3], const float p2[3],
+                                     const float origin[3], const float dir[3],
+                                     float *t, float normal[3], float bary[3])
+{
+    Ray r; r.origin = v3_from(origin); r.direction = v3_from(dir);
+    HitRecord h = triangle_ray_intersect(v3_from(p0), v3_from(p1), v3_from(p2), r);
+    if (!h.hit) return 0;
+    *t = h.distance;
+    normal[0] = h.normal.x; normal[1] = h.normal.y; normal[2] = h.normal.z;
+    bary[0] = h.barycentric.x; bary[1] = h.barycentric.y; bary[2] = h.barycentric.z;
+    return 1;
+}
+
+OR_API int or_sphere_ray_intersect(const float center[3], float radius, const float origin[3], const float dir[3],
+                                   float *t, float normal[3])
+{
+    Ray r; r.origin = v3_from(origin); r.direction = v3_from(dir);
+    HitRecord h = sphere_ray_intersect(v3_from(center), radius, r);
+    if (!h.hit) return 0;
+    *t = h.distance;
+    normal[0] = h.normal.x; normal[1] = h.normal.y; normal[2] = h.normal.z;
+    return 1;
+}
+
+OR_API float or_to_non_linear_depth(float t) { return to_non_linear_depth(t); }
+OR_API uint8_t or_unorm8(float c) { return unorm8(c); }
+OR_API void or_srgb_lut(float lut[256]) { build_srgb_lut(lut); }
+OR_API void or_tex_sample(const uint8_t *rgba, uint32_t w, uint32_t h, float u, float v, float out[3])
+{
+    Tex t; t.rgba = rgba; t.w = w; t.h = h; build_srgb_lut(t.lut);
+    v3 c = tex_sample_bilinear(&t, u, v);
+    out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+
+/* ----------------------------------------------- host-side camera maths -- */
+/* cgmath 0.18.0 is not vendored in /root/reference; these restate its
+ * published formulas with Rust's evaluation order (no fusion). */
+typedef struct { float m[4][4]; } M4; /* column-major [col][row] */
+
+static inline float cg_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 cg_cross(v3 a, v3 b)
+{
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float cg_magnitude(v3 a) { return sqrtf(cg_dot(a, a)); }
+static inline v3 cg_normalize(v3 a) { return scale3(a, 1.0f / cg_magnitude(a)); } /* normalize_to(1) */
+
+/* Matrix4::look_to_rh(eye, center - eye, up) — camera.rs:15,21 */
+static M4 cg_look_at_rh(v3 eye, v3 center, v3 up)
+{
+    v3 f = cg_normalize(sub3(center, eye));
+    v3 s = cg_normalize(cg_cross(f, up));
+    v3 u = cg_cross(s, f);
+    M4 r = {{{s.x, u.x, -f.x, 0.0f},
+             {s.y, u.y, -f.y, 0.0f},
+             {s.z, u.z, -f.z, 0.0f},
+             {-cg_dot(eye, s), -cg_dot(eye, u), cg_dot(eye, f), 1.0f}}};
+    return r;
+}
+
+/* cgmath::perspective(Deg(fovy), aspect, near, far) — camera.rs:16,27 */
+static M4 cg_perspective(float fovy_deg, float aspect, float near, float far)
+{
+    float fovy_rad = fovy_deg * (float)(3.14159265358979323846 / 180.0);
+    float f = 1.0f / tanf(fovy_rad / 2.0f);
+    M4 r;
+    memset(&r, 0, sizeof r);
+    r.m[0][0] = f / aspect;
+    r.m[1][1] = f;
+    r.m[2][2] = (far + near) / (near - far);
+    r.m[2][3] = -1.0f;
+    r.m[3][2] = (2.0f * far * near) / (near - far);
+    return r;
+}
+
+static inline float det3(float a00, float a01, float a02, float a10, float a11, float a12, float a20, float a21, float a22)
+{
+    /* columns a0*, a1*, a2* */
+    return a00 * (a11 * a22 - a21 * a12) - a10 * (a01 * a22 - a21 * a02) + a20 * (a01 * a12 - a11 * a02);
+}
+
+/* Matrix4::invert: adjugate / determinant. Returns 0 when singular. */
+static int cg_invert(const M4 *a, M4 *out)
+{
+    const float (*m)[4] = a->m;
+    float cof[4][4]; /* cof[c][r]: cofactor of element (col c,row r) */
+    for (int c = 0; c < 4; c++) {
+        for (int r = 0; r < 4; r++) {
+            float s[3][3];
+            int cc = 0;
+            for (int c2 = 0; c2 < 4; c2++) {
+                if (c2 == c) continue;
+                int rr = 0;
+                for (int r2 = 0; r2 < 4; r2++) {
+                    if (r2 == r) continue;
+                    s[cc][rr++] = m[c2][r2];
+                }
+                cc++;
+            }
+            float d = det3(s[0][0], s[0][1], s[0][2], s[1][0], s[1][1], s[1][2], s[2][0], s[2][1], s[2][2]);
+            cof[c][r] = ((c + r) & 1) ? -d : d;
+        }
+    }
+    float det = m[0][0] * cof[0][0] + m[1][0] * cof[1][0] + m[2][0] * cof[2][0] + m[3][0] * cof[3][0];
+    if (det == 0.0f) return 0;
+    float inv_det = 1.0f / det;
+    /* inverse = adjugate/det; adjugate = transpose of cofactor matrix */
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++)
+            out->m[c][r] = cof[r][c] * inv_det;
+    return 1;
+}
+
+static M4 cg_mul(const M4 *a, const M4 *b)
+{
+    M4 r;
+    for (int c = 0; c < 4; c++)
+        for (int i = 0; i < 4; i++)
+            r.m[c][i] = a->m[0][i] * b->m[c][0] + a->m[1][i] * b->m[c][1] + a->m[2][i] * b->m[c][2] + a->m[3][i] * b->m[c][3];
+    return r;
+}
+
+/* CameraInvUniform::update_view_proj — src/lib.rs:105-111 (note G * P^-1, the quirk). */
+OR_API int or_camera_build_inv_uniform(const OrCamera *cam, OrCameraInvUniform *out)
+{
+    static const M4 G = {{{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 0.5f, 0}, {0, 0, 0.5f, 1}}}; /* lib.rs:31-37 */
+    M4 view = cg_look_at_rh(v3_from(cam->eye), v3_from(cam->target), v3_from(cam->up));
+    M4 proj = cg_perspective(cam->fovy, cam->aspect, cam->znear, cam->zfar);
+    M4 view_inv, proj_inv;
+    if (!cg_invert(&view, &view_inv)) return -1;
+    if (!cg_invert(&proj, &proj_inv)) return -1;
+    M4 gp = cg_mul(&G, &proj_inv);
+    memcpy(out->viewmodel_inv, view_inv.m, sizeof view_inv.m);
+    memcpy(out->proj_inv, gp.m, sizeof gp.m);
+    out->origin[0] = cam->eye[0]; out->origin[1] = cam->eye[1]; out->origin[2] = cam->eye[2];
+    out->_padding = 0;
+    return 0;
+}
+
+/* CircleCameraController::update_camera — src/circle_camera_control.rs:76-105.
+ * keys bit0 forward, bit1 backward, bit2 left, bit3 right (up/down are recorded
+ * by the reference but never used). */
+OR_API void or_controller_update(float speed, uint32_t keys, OrCamera *camera)
+{
+    v3 eye = v3_from(camera->eye), target = v3_from(camera->target), up = v3_from(camera->up);
+    v3 forward = sub3(target, eye);
+    v3 forward_norm = cg_normalize(forward);
+    float forward_mag = cg_magnitude(forward);
+    if ((keys & 1u) && forward_mag > speed) eye = add3(eye, scale3(forward_norm, speed));
+    if (keys & 2u) eye = sub3(eye, scale3(forward_norm, speed));
+    v3 right = cg_cross(forward_norm, up);
+    forward = sub3(target, eye);
+    forward_mag = cg_magnitude(forward);
+    if (keys & 8u) eye = sub3(target, scale3(cg_normalize(add3(forward, scale3(right, speed))), forward_mag));
+    if (keys & 4u) eye = sub3(target, scale3(cg_normalize(sub3(forward, scale3(right, speed))), forward_mag));
+    camera->eye[0] = eye.x; camera->eye[1] = eye.y; camera->eye[2] = eye.z;
+}
+
+OR_API int or_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,312 @@
+"""Python driver for librwr_hip.so (tests, bench.py, smoke) — thin ctypes over the C ABI.
+
+The product is the shared library declared in include/rwr_hip.h (HIP kernels for
+gfx950 + host code in C++); this module only marshals numpy arrays across that
+boundary.  There is NO CPU fallback: if the library is missing or no GPU is
+visible, construction of a `Context` raises.
+
+The directory name contains '-', so it is imported through
+`__graft_entry__.load_package()` under the module name `rwr_amd`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librwr_hip.so")
+RES_DIR = os.path.join(_HERE, "res")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rwr_hip.h")
+
+# ---- PODs (layout-identical to include/rwr_hip.h and the reference's #[repr(C)] structs)
+CAMERA_INV_DTYPE = np.dtype(
+    [("viewmodel_inv", "<f4", (4, 4)), ("proj_inv", "<f4", (4, 4)), ("origin", "<f4", (3,)), ("_padding", "<u4")])
+SCREEN_DTYPE = np.dtype([("width", "<u4"), ("height", "<u4")])
+VERTEX_DTYPE = np.dtype([("position", "<f4", (3,)), ("pad0", "<f4"), ("tex_coords", "<f4", (2,)), ("pad1", "<f4", (2,))])
+FACE_DTYPE = np.dtype([("indices", "<u4", (3,)), ("pad0", "<u4")])
+MATERIAL_DTYPE = np.dtype([("ambient", "<f4", (3,)), ("pad0", "<f4"), ("diffuse", "<f4", (3,)), ("pad1", "<f4"),
+                           ("specular", "<f4", (3,)), ("pad2", "<f4")])
+SPHERE_DTYPE = np.dtype([("center", "<f4", (3,)), ("radius", "<f4")])
+INSTANCE_DTYPE = np.dtype([("model", "<f4", (4, 4))])
+CAMERA_DTYPE = np.dtype([("eye", "<f4", (3,)), ("target", "<f4", (3,)), ("up", "<f4", (3,)),
+                         ("aspect", "<f4"), ("fovy", "<f4"), ("znear", "<f4"), ("zfar", "<f4")])
+PARAMS_DTYPE = np.dtype([("spp", "<u4"), ("max_bounces", "<u4"), ("seed", "<u4"), ("flags", "<u4")])
+assert (CAMERA_INV_DTYPE.itemsize, VERTEX_DTYPE.itemsize, FACE_DTYPE.itemsize, MATERIAL_DTYPE.itemsize,
+        SPHERE_DTYPE.itemsize, INSTANCE_DTYPE.itemsize, CAMERA_DTYPE.itemsize) == (144, 32, 16, 48, 16, 64, 52)
+
+FLAG_AUX_OUTPUTS, FLAG_NO_CULL, FLAG_USE_BVH = 1, 2, 4
+KEY_FORWARD, KEY_BACKWARD, KEY_LEFT, KEY_RIGHT, KEY_UP, KEY_DOWN = 1, 2, 4, 8, 16, 32
+OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NOT_READY, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+
+# reference scene literals: src/lib.rs:352-361, 532-534
+REFERENCE_SPHERES = [((0.6, 0.5, -4.0), 0.4), ((0.4, 0.4, -3.0), 0.4)]
+CONTROLLER_SPEED = 0.2
+
+
+class RwrError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"rwr error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def build(force: bool = False) -> str:
+    """Compile librwr_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _HERE, "-j4"] + (["-B"] if force else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building librwr_hip.so failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads librwr_hip.so.  torch is imported first so that the process binds ONE
+    libamdhip64 (torch ships its own copy with the same SONAME)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the render path)")
+    try:
+        import torch  # noqa: F401  (HIP runtime provider)
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int, C.c_float
+    L.rwr_last_error_string.restype = C.c_char_p
+    L.rwr_ctx_get_stream.restype = vp
+    for name in ("rwr_model_vertices", "rwr_model_faces", "rwr_model_material", "rwr_model_texture_rgba8"):
+        getattr(L, name).restype = vp
+        getattr(L, name).argtypes = [vp]
+    sigs = {
+        "rwr_ctx_create": [i32, vp], "rwr_ctx_destroy": [vp], "rwr_device_count": [vp],
+        "rwr_ctx_device_info": [vp, vp, C.c_size_t, vp, vp], "rwr_ctx_set_stream": [vp, vp], "rwr_ctx_get_stream": [vp],
+        "rwr_scene_upload_mesh": [vp, vp, u32, vp, u32, vp, vp, u32, u32],
+        "rwr_scene_set_spheres": [vp, vp, u32], "rwr_scene_set_instances": [vp, vp, u32],
+        "rwr_resize": [vp, vp], "rwr_render": [vp, vp, vp], "rwr_render_rows": [vp, vp, vp, u32, u32],
+        "rwr_synchronize": [vp], "rwr_readback": [vp, vp, vp, vp, vp, vp], "rwr_get_device_targets": [vp, vp, vp],
+        "rwr_timer_begin": [vp], "rwr_timer_end": [vp, vp], "rwr_last_render_stats": [vp, vp, vp],
+        "rwr_camera_build_inv_uniform": [vp, vp], "rwr_circle_controller_update": [f32, u32, vp],
+        "rwr_load_model_compute": [C.c_char_p, C.c_char_p, vp], "rwr_model_free": [vp],
+        "rwr_model_info": [vp, vp, vp, vp, vp, vp, vp], "rwr_scene_upload_model": [vp, vp],
+        "rwr_decode_image_rgba8": [vp, C.c_size_t, vp, vp, vp], "rwr_free": [vp],
+        "rwr_make_instance_grid": [u32, f32, vp],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        if name not in ("rwr_ctx_destroy", "rwr_model_free", "rwr_free", "rwr_ctx_get_stream"):
+            fn.restype = C.c_int
+        elif name != "rwr_ctx_get_stream":
+            fn.restype = None
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != OK:
+        raise RwrError(rc, lib().rwr_last_error_string().decode("utf-8", "replace"))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------ host surface --
+def make_camera(eye=(0, 0, 0), target=(0, 0, -1), up=(0, 1, 0), aspect=1.0, fovy=60.0, znear=0.1, zfar=100.0):
+    """Camera literal of src/lib.rs:352-360 by default."""
+    cam = np.zeros(1, dtype=CAMERA_DTYPE)
+    cam["eye"], cam["target"], cam["up"] = eye, target, up
+    cam["aspect"], cam["fovy"], cam["znear"], cam["zfar"] = aspect, fovy, znear, zfar
+    return cam
+
+
+def camera_build_inv_uniform(cam: np.ndarray) -> np.ndarray:
+    out = np.zeros(1, dtype=CAMERA_INV_DTYPE)
+    _check(lib().rwr_camera_build_inv_uniform(_p(cam), _p(out)))
+    return out
+
+
+def circle_controller_update(cam: np.ndarray, keys: int, speed: float = CONTROLLER_SPEED) -> np.ndarray:
+    cam = cam.copy()
+    _check(lib().rwr_circle_controller_update(speed, keys, _p(cam)))
+    return cam
+
+
+def make_screen(w: int, h: int) -> np.ndarray:
+    s = np.zeros(1, dtype=SCREEN_DTYPE)
+    s["width"], s["height"] = w, h
+    return s
+
+
+def make_spheres(spec=REFERENCE_SPHERES) -> np.ndarray:
+    s = np.zeros(len(spec), dtype=SPHERE_DTYPE)
+    for i, (c, r) in enumerate(spec):
+        s[i]["center"], s[i]["radius"] = c, r
+    return s
+
+
+def make_params(spp=1, max_bounces=0, seed=0, flags=0) -> np.ndarray:
+    p = np.zeros(1, dtype=PARAMS_DTYPE)
+    p["spp"], p["max_bounces"], p["seed"], p["flags"] = spp, max_bounces, seed, flags
+    return p
+
+
+def make_instance_grid(per_row: int, space_between: float = 3.0) -> np.ndarray:
+    out = np.zeros(per_row * per_row, dtype=INSTANCE_DTYPE)
+    _check(lib().rwr_make_instance_grid(per_row, space_between, _p(out)))
+    return out
+
+
+def decode_image_rgba8(data: bytes) -> np.ndarray:
+    buf = np.frombuffer(data, dtype=np.uint8)
+    out = C.c_void_p()
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(lib().rwr_decode_image_rgba8(_p(buf), len(data), C.byref(out), C.byref(w), C.byref(h)))
+    try:
+        arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib().rwr_free(out)
+    return arr
+
+
+def load_model_compute(file_name: str, res_dir: str = RES_DIR) -> dict:
+    """resources::load_model_compute through the C ABI; returns numpy copies of
+    meshes[0] / materials[0] (what TriangleList consumes)."""
+    L = lib()
+    h = C.c_void_p()
+    _check(L.rwr_load_model_compute(res_dir.encode(), file_name.encode(), C.byref(h)))
+    try:
+        n = [C.c_uint32() for _ in range(6)]
+        _check(L.rwr_model_info(h, *[C.byref(x) for x in n]))
+        n_meshes, n_materials, n_verts, n_faces, tw, th = [x.value for x in n]
+        verts = np.frombuffer(C.string_at(L.rwr_model_vertices(h), n_verts * 32), dtype=VERTEX_DTYPE).copy()
+        faces = np.frombuffer(C.string_at(L.rwr_model_faces(h), n_faces * 16), dtype=FACE_DTYPE).copy()
+        material = np.frombuffer(C.string_at(L.rwr_model_material(h), 48), dtype=MATERIAL_DTYPE).copy()
+        tex = np.frombuffer(C.string_at(L.rwr_model_texture_rgba8(h), tw * th * 4), dtype=np.uint8).reshape(th, tw, 4).copy()
+    finally:
+        L.rwr_model_free(h)
+    return {"vertices": verts, "faces": faces, "material": material, "texture": tex,
+            "n_meshes": n_meshes, "n_materials": n_materials}
+
+
+# ------------------------------------------------------------------------ context --
+def device_count() -> int:
+    n = C.c_int()
+    lib().rwr_device_count(C.byref(n))
+    return n.value
+
+
+class Context:
+    """One GPU, one HIP stream (rwr_context)."""
+
+    def __init__(self, device_id: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().rwr_ctx_create(device_id, C.byref(self._h)))
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rwr_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cu, ws = C.c_int(), C.c_int()
+        _check(lib().rwr_ctx_device_info(self._h, name, 256, C.byref(cu), C.byref(ws)))
+        return {"name": name.value.decode(), "cu_count": cu.value, "wave_size": ws.value}
+
+    def set_stream(self, hip_stream: int | None):
+        _check(lib().rwr_ctx_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def upload_mesh(self, vertices, faces, material, texture):
+        vertices = np.ascontiguousarray(vertices, dtype=VERTEX_DTYPE)
+        faces = np.ascontiguousarray(faces, dtype=FACE_DTYPE)
+        material = np.ascontiguousarray(material, dtype=MATERIAL_DTYPE)
+        texture = np.ascontiguousarray(texture, dtype=np.uint8)
+        th, tw = texture.shape[:2] if texture.ndim == 3 else (0, 0)
+        _check(lib().rwr_scene_upload_mesh(self._h, _p(vertices), len(vertices), _p(faces), len(faces),
+                                           _p(material), _p(texture), tw, th))
+
+    def upload_model(self, model: dict):
+        self.upload_mesh(model["vertices"], model["faces"], model["material"], model["texture"])
+
+    def set_spheres(self, spheres):
+        spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        _check(lib().rwr_scene_set_spheres(self._h, _p(spheres) if len(spheres) else None, len(spheres)))
+
+    def set_instances(self, instances):
+        n = 0 if instances is None else len(instances)
+        arr = None if n == 0 else np.ascontiguousarray(instances, dtype=INSTANCE_DTYPE)
+        _check(lib().rwr_scene_set_instances(self._h, _p(arr), n))
+
+    def resize(self, width: int, height: int):
+        _check(lib().rwr_resize(self._h, _p(make_screen(width, height))))
+        self.width, self.height = width, height
+
+    def render(self, cam_inv, params=None, rows=None):
+        if rows is None:
+            _check(lib().rwr_render(self._h, _p(cam_inv), _p(params)))
+        else:
+            _check(lib().rwr_render_rows(self._h, _p(cam_inv), _p(params), rows[0], rows[1]))
+
+    def synchronize(self):
+        _check(lib().rwr_synchronize(self._h))
+
+    def readback(self, aux: bool = False) -> dict:
+        h, w = self.height, self.width
+        out = {"color": np.zeros((h, w, 4), np.uint8), "depth": np.zeros((h, w), np.float32)}
+        if aux:
+            out["color_f32"] = np.zeros((h, w, 4), np.float32)
+            out["obj_id"] = np.zeros((h, w), np.int32)
+            out["hit_t"] = np.zeros((h, w), np.float32)
+        _check(lib().rwr_readback(self._h, _p(out["color"]), _p(out["depth"]), _p(out.get("color_f32")),
+                                  _p(out.get("obj_id")), _p(out.get("hit_t"))))
+        return out
+
+    def device_targets(self) -> tuple[int, int]:
+        a, b = C.c_void_p(), C.c_void_p()
+        _check(lib().rwr_get_device_targets(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def timer_begin(self):
+        _check(lib().rwr_timer_begin(self._h))
+
+    def timer_end(self) -> float:
+        ms = C.c_float()
+        _check(lib().rwr_timer_end(self._h, C.byref(ms)))
+        return ms.value
+
+    def last_render_stats(self) -> tuple[int, int]:
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().rwr_last_render_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+def exported_symbols_declared_in_header() -> list[str]:
+    """Names of every RWR_API function declared in include/rwr_hip.h."""
+    import re
+
+    with open(HEADER_PATH, "r") as fh:
+        text = fh.read()
+    return sorted(set(re.findall(r"RWR_API\s+[^;(]*?\b(rwr_[a-z0-9_]+)\s*\(", text)))

@@ -1,0 +1,441 @@
+// C-ABI implementation: context, scene upload, frame orchestration.
+// Replaces the wgpu plumbing of State (/root/reference/src/lib.rs:260-1231) with
+// one HIP stream and a handful of device buffers.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rwr_internal.h"
+
+namespace rwr {
+
+static thread_local std::string g_last_error;
+
+int set_error(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define RWR_HIP_CHECK(expr)                                                                          \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return set_error(RWR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+struct DeviceBuffer {
+    T *ptr = nullptr;
+    size_t count = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= count && ptr) return hipSuccess;
+        release();
+        if (n == 0) return hipSuccess;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T));
+        if (e == hipSuccess) count = n;
+        else ptr = nullptr;
+        return e;
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+};
+
+}  // namespace rwr
+
+using namespace rwr;
+
+struct rwr_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+
+    // scene
+    DeviceBuffer<rwr_model_vertex_small> d_verts;
+    DeviceBuffer<rwr_model_face_small> d_faces;
+    DeviceBuffer<rwr_instance_raw> d_instances;
+    DeviceBuffer<TriRecord> d_tris;
+    DeviceBuffer<FaceUV> d_face_uv;
+    DeviceBuffer<uint32_t> d_tex;
+    DeviceBuffer<float> d_lut;
+    uint32_t n_verts = 0, n_faces = 0, n_instances = 0, n_tris = 0;
+    uint32_t tex_w = 0, tex_h = 0;
+    rwr_material_data material{};
+    bool have_mesh = false;
+    bool tris_dirty = false;
+    rwr_sphere_buffer_data spheres[RWR_MAX_SPHERES]{};
+    uint32_t n_spheres = 0;
+
+    // targets
+    rwr_screen screen{0, 0};
+    DeviceBuffer<uint8_t> d_color;
+    DeviceBuffer<float> d_depth;
+    DeviceBuffer<float> d_color_f32;
+    DeviceBuffer<int32_t> d_obj_id;
+    DeviceBuffer<float> d_hit_t;
+    bool aux_valid = false;
+
+    uint64_t last_primary = 0, last_bounce = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+void build_srgb_lut(float *lut)
+{
+    // Rgba8UnormSrgb decode (texture.rs:122): the sRGB EOTF, evaluated in double.
+    for (int i = 0; i < 256; i++) {
+        const double c = (double)i / 255.0;
+        const double l = (c <= 0.04045) ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4);
+        lut[i] = (float)l;
+    }
+}
+
+int rebuild_tris(rwr_context *ctx)
+{
+    if (!ctx->tris_dirty) return RWR_OK;
+    const uint32_t total = ctx->n_faces * (ctx->n_instances ? ctx->n_instances : 1u);
+    RWR_HIP_CHECK(ctx->d_tris.ensure(total));
+    RWR_HIP_CHECK(ctx->d_face_uv.ensure(total));
+    RWR_HIP_CHECK(launch_prebake(ctx->stream, ctx->d_verts.ptr, ctx->d_faces.ptr, ctx->n_faces, ctx->d_instances.ptr,
+                                 ctx->n_instances, ctx->d_tris.ptr, ctx->d_face_uv.ptr));
+    ctx->n_tris = total;
+    ctx->tris_dirty = false;
+    return RWR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rwr_last_error_string(void) { return g_last_error.c_str(); }
+
+int rwr_device_count(int *out_count)
+{
+    if (!out_count) return set_error(RWR_ERR_INVALID_ARGUMENT, "out_count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out_count = 0;
+        return set_error(RWR_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *out_count = n;
+    return RWR_OK;
+}
+
+int rwr_ctx_create(int device_id, rwr_context **out_ctx)
+{
+    if (!out_ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return set_error(RWR_ERR_HIP, "no HIP device available (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n)
+        return set_error(RWR_ERR_INVALID_ARGUMENT, "device_id %d out of range [0,%d)", device_id, n);
+    rwr_context *ctx = new (std::nothrow) rwr_context();
+    if (!ctx) return set_error(RWR_ERR_HIP, "out of host memory");
+    ctx->device = device_id;
+    DeviceGuard g(device_id);
+    if (!g.ok) {
+        delete ctx;
+        return set_error(RWR_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+    }
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_begin)) != hipSuccess || (e = hipEventCreate(&ctx->ev_end)) != hipSuccess) {
+        rwr_ctx_destroy(ctx);
+        return set_error(RWR_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
+    }
+    ctx->stream = ctx->own_stream;
+    float lut[256];
+    build_srgb_lut(lut);
+    if ((e = ctx->d_lut.ensure(256)) != hipSuccess ||
+        (e = hipMemcpy(ctx->d_lut.ptr, lut, sizeof lut, hipMemcpyHostToDevice)) != hipSuccess) {
+        rwr_ctx_destroy(ctx);
+        return set_error(RWR_ERR_HIP, "sRGB table upload failed: %s", hipGetErrorString(e));
+    }
+    *out_ctx = ctx;
+    return RWR_OK;
+}
+
+void rwr_ctx_destroy(rwr_context *ctx)
+{
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
+    ctx->d_tris.release(); ctx->d_face_uv.release(); ctx->d_tex.release(); ctx->d_lut.release();
+    ctx->d_color.release(); ctx->d_depth.release(); ctx->d_color_f32.release();
+    ctx->d_obj_id.release(); ctx->d_hit_t.release();
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int rwr_ctx_device_info(rwr_context *ctx, char *name, size_t name_cap, int *cu_count, int *wave_size)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    hipDeviceProp_t prop;
+    RWR_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_cap) {
+        std::snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (wave_size) *wave_size = prop.warpSize;
+    return RWR_OK;
+}
+
+int rwr_ctx_set_stream(rwr_context *ctx, void *hip_stream)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return RWR_OK;
+}
+
+void *rwr_ctx_get_stream(rwr_context *ctx) { return ctx ? reinterpret_cast<void *>(ctx->stream) : nullptr; }
+
+int rwr_scene_upload_mesh(rwr_context *ctx, const rwr_model_vertex_small *verts, uint32_t n_verts,
+                          const rwr_model_face_small *faces, uint32_t n_faces, const rwr_material_data *material,
+                          const uint8_t *rgba8_srgb, uint32_t tex_w, uint32_t tex_h)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (n_faces > 0) {
+        if (!verts || !faces || !material || !rgba8_srgb)
+            return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL mesh array with n_faces = %u", n_faces);
+        if (n_verts == 0 || tex_w == 0 || tex_h == 0)
+            return set_error(RWR_ERR_INVALID_ARGUMENT, "empty vertex array or texture with n_faces = %u", n_faces);
+        // The shader indexes vertice_list unchecked (compute.wgsl:191-193); an
+        // out-of-range index would be a GPU fault here, so it is rejected up front.
+        for (uint32_t f = 0; f < n_faces; f++)
+            for (int k = 0; k < 3; k++)
+                if (faces[f].indices[k] >= n_verts)
+                    return set_error(RWR_ERR_INVALID_ARGUMENT, "face %u index %u out of range (n_verts %u)", f,
+                                     faces[f].indices[k], n_verts);
+        if ((uint64_t)n_faces * (ctx->n_instances ? ctx->n_instances : 1u) > 0x7fffffffull)
+            return set_error(RWR_ERR_INVALID_ARGUMENT, "too many faces");
+    }
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->have_mesh = false;
+    ctx->n_faces = n_faces;
+    ctx->n_verts = n_verts;
+    ctx->n_tris = 0;
+    if (n_faces == 0) {
+        ctx->have_mesh = true;
+        ctx->tris_dirty = false;
+        return RWR_OK;
+    }
+    RWR_HIP_CHECK(ctx->d_verts.ensure(n_verts));
+    RWR_HIP_CHECK(ctx->d_faces.ensure(n_faces));
+    RWR_HIP_CHECK(ctx->d_tex.ensure((size_t)tex_w * tex_h));
+    RWR_HIP_CHECK(hipMemcpy(ctx->d_verts.ptr, verts, (size_t)n_verts * sizeof *verts, hipMemcpyHostToDevice));
+    RWR_HIP_CHECK(hipMemcpy(ctx->d_faces.ptr, faces, (size_t)n_faces * sizeof *faces, hipMemcpyHostToDevice));
+    RWR_HIP_CHECK(hipMemcpy(ctx->d_tex.ptr, rgba8_srgb, (size_t)tex_w * tex_h * 4, hipMemcpyHostToDevice));
+    ctx->material = *material;
+    ctx->tex_w = tex_w;
+    ctx->tex_h = tex_h;
+    ctx->have_mesh = true;
+    ctx->tris_dirty = true;
+    return rebuild_tris(ctx);
+}
+
+int rwr_scene_set_spheres(rwr_context *ctx, const rwr_sphere_buffer_data *spheres, uint32_t n)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (n > RWR_MAX_SPHERES) return set_error(RWR_ERR_INVALID_ARGUMENT, "at most %d spheres", RWR_MAX_SPHERES);
+    if (n && !spheres) return set_error(RWR_ERR_INVALID_ARGUMENT, "spheres is NULL");
+    for (uint32_t i = 0; i < n; i++) ctx->spheres[i] = spheres[i];
+    ctx->n_spheres = n;
+    return RWR_OK;
+}
+
+int rwr_scene_set_instances(rwr_context *ctx, const rwr_instance_raw *instances, uint32_t n)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (n && !instances) return set_error(RWR_ERR_INVALID_ARGUMENT, "instances is NULL");
+    if ((uint64_t)ctx->n_faces * (n ? n : 1u) > 0x7fffffffull) return set_error(RWR_ERR_INVALID_ARGUMENT, "too many faces");
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (n) {
+        RWR_HIP_CHECK(ctx->d_instances.ensure(n));
+        RWR_HIP_CHECK(hipMemcpy(ctx->d_instances.ptr, instances, (size_t)n * sizeof *instances, hipMemcpyHostToDevice));
+    }
+    ctx->n_instances = n;
+    if (ctx->have_mesh && ctx->n_faces) {
+        ctx->tris_dirty = true;
+        return rebuild_tris(ctx);
+    }
+    return RWR_OK;
+}
+
+int rwr_resize(rwr_context *ctx, const rwr_screen *screen)
+{
+    if (!ctx || !screen) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    // resize ignores zero sizes (lib.rs:773); here that is an explicit error.
+    if (screen->width == 0 || screen->height == 0) return set_error(RWR_ERR_INVALID_ARGUMENT, "zero-sized screen");
+    if ((uint64_t)screen->width * screen->height > (1ull << 30)) return set_error(RWR_ERR_INVALID_ARGUMENT, "screen too large");
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const size_t n = (size_t)screen->width * screen->height;
+    RWR_HIP_CHECK(ctx->d_color.ensure(n * 4));
+    RWR_HIP_CHECK(ctx->d_depth.ensure(n));
+    // the reference's textures start zeroed and are cleared every frame
+    RWR_HIP_CHECK(hipMemsetAsync(ctx->d_color.ptr, 0, n * 4, ctx->stream));
+    RWR_HIP_CHECK(hipMemsetAsync(ctx->d_depth.ptr, 0, n * sizeof(float), ctx->stream));
+    ctx->screen = *screen;
+    ctx->aux_valid = false;
+    return RWR_OK;
+}
+
+int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, const rwr_render_params *params,
+                    uint32_t row_begin, uint32_t row_end)
+{
+    if (!ctx || !camera) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (ctx->screen.width == 0) return set_error(RWR_ERR_NOT_READY, "rwr_resize has not been called");
+    if (!ctx->have_mesh) return set_error(RWR_ERR_NOT_READY, "rwr_scene_upload_mesh has not been called");
+    if (row_begin > row_end || row_end > ctx->screen.height)
+        return set_error(RWR_ERR_INVALID_ARGUMENT, "row band [%u,%u) outside the %u-row frame", row_begin, row_end,
+                         ctx->screen.height);
+    rwr_render_params rp = {1, 0, 0, 0};
+    if (params) rp = *params;
+    if (rp.spp == 0) return set_error(RWR_ERR_INVALID_ARGUMENT, "spp must be >= 1");
+    if (rp.max_bounces > 1) return set_error(RWR_ERR_UNSUPPORTED, "max_bounces > 1 is not supported");
+    if (rp.spp != 1 || rp.max_bounces != 0 || (rp.flags & RWR_FLAG_USE_BVH))
+        return set_error(RWR_ERR_UNSUPPORTED, "the wavefront integrator is not built into this library yet");
+
+    DeviceGuard g(ctx->device);
+    const size_t n = (size_t)ctx->screen.width * ctx->screen.height;
+    const bool aux = (rp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
+    if (aux) {
+        RWR_HIP_CHECK(ctx->d_color_f32.ensure(n * 4));
+        RWR_HIP_CHECK(ctx->d_obj_id.ensure(n));
+        RWR_HIP_CHECK(ctx->d_hit_t.ensure(n));
+    }
+    int rc = rebuild_tris(ctx);
+    if (rc != RWR_OK) return rc;
+
+    FrameParams fp{};
+    fp.cam = *camera;
+    fp.width = ctx->screen.width;
+    fp.height = ctx->screen.height;
+    fp.row_begin = row_begin;
+    fp.row_end = row_end;
+    fp.n_spheres = ctx->n_spheres;
+    for (uint32_t i = 0; i < ctx->n_spheres; i++) fp.spheres[i] = ctx->spheres[i];
+    fp.n_tris = ctx->n_tris;
+    fp.tex_w = ctx->tex_w;
+    fp.tex_h = ctx->tex_h;
+    fp.flags = rp.flags;
+    for (int k = 0; k < 3; k++) {
+        fp.ambient[k] = ctx->material.ambient[k];
+        fp.specular[k] = ctx->material.specular[k];
+    }
+    Targets tg{ctx->d_color.ptr, ctx->d_depth.ptr, aux ? ctx->d_color_f32.ptr : nullptr,
+               aux ? ctx->d_obj_id.ptr : nullptr, aux ? ctx->d_hit_t.ptr : nullptr};
+    RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_tex.ptr, ctx->d_lut.ptr, tg));
+    ctx->aux_valid = aux;
+    ctx->last_primary = (uint64_t)ctx->screen.width * (row_end - row_begin);
+    ctx->last_bounce = 0;
+    return RWR_OK;
+}
+
+int rwr_render(rwr_context *ctx, const rwr_camera_inv_uniform *camera, const rwr_render_params *params)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    return rwr_render_rows(ctx, camera, params, 0, ctx->screen.height);
+}
+
+int rwr_synchronize(rwr_context *ctx)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RWR_OK;
+}
+
+int rwr_readback(rwr_context *ctx, uint8_t *rgba8, float *depth, float *rgba_f32, int32_t *obj_id, float *hit_t)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (ctx->screen.width == 0) return set_error(RWR_ERR_NOT_READY, "rwr_resize has not been called");
+    if ((rgba_f32 || obj_id || hit_t) && !ctx->aux_valid)
+        return set_error(RWR_ERR_NOT_READY, "aux planes requested but the last render did not set RWR_FLAG_AUX_OUTPUTS");
+    DeviceGuard g(ctx->device);
+    const size_t n = (size_t)ctx->screen.width * ctx->screen.height;
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (rgba8) RWR_HIP_CHECK(hipMemcpy(rgba8, ctx->d_color.ptr, n * 4, hipMemcpyDeviceToHost));
+    if (depth) RWR_HIP_CHECK(hipMemcpy(depth, ctx->d_depth.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (rgba_f32) RWR_HIP_CHECK(hipMemcpy(rgba_f32, ctx->d_color_f32.ptr, n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    if (obj_id) RWR_HIP_CHECK(hipMemcpy(obj_id, ctx->d_obj_id.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (hit_t) RWR_HIP_CHECK(hipMemcpy(hit_t, ctx->d_hit_t.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+    return RWR_OK;
+}
+
+int rwr_get_device_targets(rwr_context *ctx, void **d_rgba8, void **d_depth)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (ctx->screen.width == 0) return set_error(RWR_ERR_NOT_READY, "rwr_resize has not been called");
+    if (d_rgba8) *d_rgba8 = ctx->d_color.ptr;
+    if (d_depth) *d_depth = ctx->d_depth.ptr;
+    return RWR_OK;
+}
+
+int rwr_timer_begin(rwr_context *ctx)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
+    return RWR_OK;
+}
+
+int rwr_timer_end(rwr_context *ctx, float *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
+    RWR_HIP_CHECK(hipEventSynchronize(ctx->ev_end));
+    RWR_HIP_CHECK(hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
+    return RWR_OK;
+}
+
+int rwr_last_render_stats(rwr_context *ctx, uint64_t *primary_rays, uint64_t *bounce_rays)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (primary_rays) *primary_rays = ctx->last_primary;
+    if (bounce_rays) *bounce_rays = ctx->last_bounce;
+    return RWR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// C-ABI wrappers over the pure-CPU host surface (camera maths, controller,
+// OBJ/MTL/texture loader, image decoding, instance grid).  The implementations
+// live in ../host/*.hpp so that C++ callers can use them directly; these entry
+// points serve FFI callers (Rust, ctypes).
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../host/camera.hpp"
+#include "../host/circle_camera_control.hpp"
+#include "../host/resources.hpp"
+#include "rwr_internal.h"
+
+using namespace rwr;
+
+struct rwr_model {
+    model::Model model;
+};
+
+extern "C" {
+
+int rwr_camera_build_inv_uniform(const rwr_camera *camera, rwr_camera_inv_uniform *out)
+{
+    if (!camera || !out) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    CameraInvUniform u;
+    if (!u.update_view_proj(Camera::from_c(*camera)))
+        return set_error(RWR_ERR_INVALID_ARGUMENT, "camera matrix is singular (the reference panics in invert().unwrap())");
+    std::memcpy(out, static_cast<const rwr_camera_inv_uniform *>(&u), sizeof *out);
+    return RWR_OK;
+}
+
+int rwr_circle_controller_update(float speed, uint32_t pressed_keys, rwr_camera *camera)
+{
+    if (!camera) return set_error(RWR_ERR_INVALID_ARGUMENT, "camera is NULL");
+    CircleCameraController ctl(speed);
+    ctl.set_pressed_mask(pressed_keys);
+    Camera c = Camera::from_c(*camera);
+    ctl.update_camera(c);
+    *camera = c.to_c();
+    return RWR_OK;
+}
+
+int rwr_load_model_compute(const char *res_dir, const char *file_name, rwr_model **out_model)
+{
+    if (!res_dir || !file_name || !out_model) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_model = nullptr;
+    rwr_model *m = new (std::nothrow) rwr_model();
+    if (!m) return set_error(RWR_ERR_IO, "out of memory");
+    resources::Error e = resources::load_model_compute(res_dir, file_name, m->model);
+    if (e) {
+        delete m;
+        return set_error(e.code, "%s", e.message.c_str());
+    }
+    // TriangleList consumes meshes[0] / materials[0] without checking (triangle_list.rs:212,229)
+    if (m->model.meshes.empty() || m->model.materials.empty()) {
+        delete m;
+        return set_error(RWR_ERR_PARSE, "%s: no mesh or no material (index out of bounds in the reference)", file_name);
+    }
+    *out_model = m;
+    return RWR_OK;
+}
+
+void rwr_model_free(rwr_model *model) { delete model; }
+
+int rwr_model_info(const rwr_model *model, uint32_t *n_meshes, uint32_t *n_materials, uint32_t *n_verts, uint32_t *n_faces,
+                   uint32_t *tex_w, uint32_t *tex_h)
+{
+    if (!model) return set_error(RWR_ERR_INVALID_ARGUMENT, "model is NULL");
+    const auto &m = model->model;
+    if (n_meshes) *n_meshes = (uint32_t)m.meshes.size();
+    if (n_materials) *n_materials = (uint32_t)m.materials.size();
+    if (n_verts) *n_verts = (uint32_t)m.meshes[0].vertex_buffer.size();
+    if (n_faces) *n_faces = (uint32_t)m.meshes[0].index_buffer.size();
+    if (tex_w) *tex_w = m.materials[0].diffuse_texture.width;
+    if (tex_h) *tex_h = m.materials[0].diffuse_texture.height;
+    return RWR_OK;
+}
+
+const rwr_model_vertex_small *rwr_model_vertices(const rwr_model *model) { return model ? model->model.meshes[0].vertex_buffer.data() : nullptr; }
+const rwr_model_face_small *rwr_model_faces(const rwr_model *model) { return model ? model->model.meshes[0].index_buffer.data() : nullptr; }
+const uint8_t *rwr_model_texture_rgba8(const rwr_model *model) { return model ? model->model.materials[0].diffuse_texture.rgba.data() : nullptr; }
+
+const rwr_material_data *rwr_model_material(const rwr_model *model)
+{
+    // MaterialData::new(materials[0].ambient, .diffuse, .specular) — triangle_list.rs:212
+    static thread_local rwr_material_data md;
+    if (!model) return nullptr;
+    const auto &m = model->model.materials[0];
+    md = rwr_material_data{{m.ambient[0], m.ambient[1], m.ambient[2]}, 0.0f, {m.diffuse[0], m.diffuse[1], m.diffuse[2]}, 0.0f,
+                           {m.specular[0], m.specular[1], m.specular[2]}, 0.0f};
+    return &md;
+}
+
+int rwr_scene_upload_model(rwr_context *ctx, const rwr_model *model)
+{
+    if (!ctx || !model) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    const auto &mesh = model->model.meshes[0];
+    const auto &tex = model->model.materials[0].diffuse_texture;
+    return rwr_scene_upload_mesh(ctx, mesh.vertex_buffer.data(), (uint32_t)mesh.vertex_buffer.size(), mesh.index_buffer.data(),
+                                 (uint32_t)mesh.index_buffer.size(), rwr_model_material(model), tex.rgba.data(), tex.width, tex.height);
+}
+
+int rwr_decode_image_rgba8(const uint8_t *bytes, size_t n_bytes, uint8_t **out_rgba, uint32_t *out_w, uint32_t *out_h)
+{
+    if (!bytes || !out_rgba || !out_w || !out_h) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_rgba = nullptr;
+    codec::Image img;
+    std::string err;
+    if (!codec::decode_image(bytes, n_bytes, img, err)) return set_error(RWR_ERR_PARSE, "%s", err.c_str());
+    uint8_t *p = static_cast<uint8_t *>(std::malloc(img.rgba.size() ? img.rgba.size() : 1));
+    if (!p) return set_error(RWR_ERR_IO, "out of memory");
+    std::memcpy(p, img.rgba.data(), img.rgba.size());
+    *out_rgba = p;
+    *out_w = img.width;
+    *out_h = img.height;
+    return RWR_OK;
+}
+
+void rwr_free(void *p) { std::free(p); }
+
+int rwr_make_instance_grid(uint32_t per_row, float space_between, rwr_instance_raw *out)
+{
+    if (!out || per_row == 0) return set_error(RWR_ERR_INVALID_ARGUMENT, "bad instance grid arguments");
+    // lib.rs:400-421
+    for (uint32_t z = 0; z < per_row; z++) {
+        for (uint32_t x = 0; x < per_row; x++) {
+            const float px = space_between * ((float)x - (float)per_row / 2.0f);
+            const float pz = space_between * ((float)z - (float)per_row / 2.0f);
+            Instance inst;
+            inst.position = Vector3(px, 0.0f, pz);
+            inst.rotation = inst.position.is_zero() ? Quaternion::from_axis_angle(Vector3::unit_z(), 0.0f)
+                                                    : Quaternion::from_axis_angle(inst.position.normalize(), 45.0f);
+            out[z * per_row + x] = inst.to_raw();
+        }
+    }
+    return RWR_OK;
+}
+
+}  // extern "C"

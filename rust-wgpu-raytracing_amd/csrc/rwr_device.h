@@ -1,0 +1,224 @@
+// Device-side restatement of the reference shaders' per-ray functions.
+//
+// ARITHMETIC CONTRACT (DESIGN.md §"Numerics"): this translation unit is built
+// with -ffp-contract=off and without fast-math; f32 divide and sqrt are the
+// IEEE-correct expansions (-fhip-fp32-correctly-rounded-divide-sqrt); f32
+// denormals are kept (gfx950 default).  Every expression that decides WHICH
+// surface a pixel shows (ray generation, hit tests, nearest selection, depth
+// compositing) is written operation-for-operation as the WGSL has it, so those
+// results are bit-identical to a literal (unfused) evaluation of the shader.
+// Conservative culling code (tile frusta, BVH boxes) is free to use FMA: it can
+// only skip faces no ray of the wave can hit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rwr_internal.h"
+
+#define RWR_DEV __device__ __forceinline__
+
+namespace rwr {
+
+struct f3 { float x, y, z; };
+
+RWR_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RWR_DEV f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+RWR_DEV f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RWR_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+RWR_DEV f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+// WGSL dot / cross, literal: products rounded, sums left to right.
+RWR_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RWR_DEV f3 cross3(f3 a, f3 b)
+{
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RWR_DEV f3 normalize3(f3 a)
+{
+    float len = sqrtf(dot3(a, a));
+    return mk3(a.x / len, a.y / len, a.z / len);
+}
+// origin + t * direction
+RWR_DEV f3 along(f3 o, float t, f3 d) { return mk3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z); }
+
+// compute.wgsl:51-53
+constexpr float kNear = 0.01f;
+constexpr float kFar = 100.0f;
+constexpr float kEpsilon = 0.000001f;
+
+// compute.wgsl:78-80
+RWR_DEV float to_non_linear_depth(float depth)
+{
+    return ((1.0f / depth) - (1.0f / kNear)) / ((1.0f / kFar) - (1.0f / kNear));
+}
+
+// mat4x4 * vec4 with column-major m[col][row]; WGSL: m[0]*v.x + m[1]*v.y + m[2]*v.z + m[3]*v.w
+RWR_DEV void mat4_mul(const float (&m)[4][4], float vx, float vy, float vz, float vw,
+                      float &rx, float &ry, float &rz, float &rw)
+{
+    rx = m[0][0] * vx + m[1][0] * vy + m[2][0] * vz + m[3][0] * vw;
+    ry = m[0][1] * vx + m[1][1] * vy + m[2][1] * vz + m[3][1] * vw;
+    rz = m[0][2] * vx + m[1][2] * vy + m[2][2] * vz + m[3][2] * vw;
+    rw = m[0][3] * vx + m[1][3] * vy + m[2][3] * vz + m[3][3] * vw;
+}
+
+// World-space direction of the ray through pixel-space point (fx, fy) BEFORE
+// normalisation — compute.wgsl:151-159.
+RWR_DEV f3 ray_dir_unnormalized(const rwr_camera_inv_uniform &cam, float fx, float fy, float width, float height)
+{
+    float x_nds = 2.0f * fx / width - 1.0f;
+    float y_nds = 2.0f * fy / height - 1.0f;
+    float vx, vy, vz, vw;
+    mat4_mul(cam.proj_inv, x_nds, y_nds, 1.0f, 1.0f, vx, vy, vz, vw);
+    vw = 0.0f;
+    float wx, wy, wz, ww;
+    mat4_mul(cam.viewmodel_inv, vx, vy, vz, vw, wx, wy, wz, ww);
+    return mk3(wx, wy, wz);
+}
+
+// pixelToRay, compute.wgsl:150-164; (jx,jy) = (0.5,0.5) in the reference.
+RWR_DEV f3 pixel_to_ray_dir(const rwr_camera_inv_uniform &cam, uint32_t x, uint32_t y, float jx, float jy,
+                            uint32_t width, uint32_t height)
+{
+    return normalize3(ray_dir_unnormalized(cam, (float)x + jx, (float)y + jy, (float)width, (float)height));
+}
+
+// sphereRayIntersect, sphere/compute.wgsl:63-85.  Returns hit; t and normal on hit.
+RWR_DEV bool sphere_ray_intersect(f3 center, float radius, f3 O, f3 D, float &t_out, f3 &n_out)
+{
+    f3 oc = sub3(O, center);
+    float a = dot3(D, D);
+    float b = 2.0f * dot3(oc, D);
+    float c = dot3(oc, oc) - (radius * radius);
+    float discriminant = b * b - 4.0f * a * c;
+    if (discriminant < 0.0f) return false;
+    float sq = sqrtf(discriminant);
+    float t1 = (-b - sq) / (2.0f * a);
+    float t2 = (-b + sq) / (2.0f * a);
+    float t;
+    if (t1 >= 0.0f) t = t1;
+    else if (t2 >= 0.0f) t = t2;
+    else return false;
+    f3 P = along(O, t, D);
+    n_out = normalize3(sub3(P, center));
+    t_out = t;
+    return true;
+}
+
+// pow(x, 32) by five squarings (x >= 0).  Within 16 ulp of the correctly rounded
+// power; colours are compared at 1e-4 absolute (DESIGN.md §"Numerics").
+RWR_DEV float pow32(float x)
+{
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8;
+    return x16 * x16;
+}
+
+// Sphere shading, sphere/compute.wgsl:137-152.
+RWR_DEV f3 shade_sphere(f3 n, f3 D)
+{
+    const f3 nl = neg3(normalize3(mk3(1.0f, -5.0f, 1.0f)));  // -normalize(kLightDir), :41
+    float diffuse = 1.0f * fmaxf(0.0f, dot3(n, nl));
+    f3 half_dir = normalize3(sub3(nl, D));
+    float specular = 0.5f * pow32(fmaxf(0.0f, dot3(half_dir, n)));
+    float k = 0.1f + diffuse;
+    return mk3(k * 1.0f + specular, k * 0.0f + specular, k * 0.0f + specular);
+}
+
+// Rgba8UnormSrgb texel fetch + bilinear filter with ClampToEdge
+// (texture.rs:122,151-159; textureSampleGrad at LOD 0, compute.wgsl:225).
+// `lut` is the 256-entry sRGB->linear table in LDS.
+RWR_DEV f3 tex_sample_bilinear(const uint32_t *__restrict__ tex, uint32_t tw, uint32_t th, const float *lut,
+                               float u, float v)
+{
+    float fx = u * (float)tw - 0.5f;
+    float fy = v * (float)th - 0.5f;
+    float x0f = floorf(fx), y0f = floorf(fy);
+    float ax = fx - x0f, ay = fy - y0f;
+    float wmax = (float)(tw - 1), hmax = (float)(th - 1);
+    uint32_t x0 = (uint32_t)fminf(fmaxf(x0f, 0.0f), wmax);
+    uint32_t x1 = (uint32_t)fminf(fmaxf(x0f + 1.0f, 0.0f), wmax);
+    uint32_t y0 = (uint32_t)fminf(fmaxf(y0f, 0.0f), hmax);
+    uint32_t y1 = (uint32_t)fminf(fmaxf(y0f + 1.0f, 0.0f), hmax);
+    uint32_t t00 = tex[y0 * tw + x0], t10 = tex[y0 * tw + x1];
+    uint32_t t01 = tex[y1 * tw + x0], t11 = tex[y1 * tw + x1];
+    float w00 = (1.0f - ax) * (1.0f - ay), w10 = ax * (1.0f - ay);
+    float w01 = (1.0f - ax) * ay, w11 = ax * ay;
+    f3 c;
+    c.x = lut[t00 & 255u] * w00 + lut[t10 & 255u] * w10 + lut[t01 & 255u] * w01 + lut[t11 & 255u] * w11;
+    c.y = lut[(t00 >> 8) & 255u] * w00 + lut[(t10 >> 8) & 255u] * w10 + lut[(t01 >> 8) & 255u] * w01 +
+          lut[(t11 >> 8) & 255u] * w11;
+    c.z = lut[(t00 >> 16) & 255u] * w00 + lut[(t10 >> 16) & 255u] * w10 + lut[(t01 >> 16) & 255u] * w01 +
+          lut[(t11 >> 16) & 255u] * w11;
+    return c;
+}
+
+// Mesh shading, triangle_list/compute.wgsl:217-234.  bary = (u, v, 1-u-v) weights
+// of (p0,p1,p2); n is the facing unit normal.  *albedo receives the texel.
+RWR_DEV f3 shade_mesh(const FaceUV &fuv, float b0, float b1, float b2, f3 n, f3 D, const float *ka, const float *ks,
+                      const uint32_t *__restrict__ tex, uint32_t tw, uint32_t th, const float *lut, f3 *albedo)
+{
+    float tu = b0 * fuv.uv0[0] + b1 * fuv.uv1[0] + b2 * fuv.uv2[0];
+    float tv = b0 * fuv.uv0[1] + b1 * fuv.uv1[1] + b2 * fuv.uv2[1];
+    tv = 1.0f - tv;
+    f3 texel = tex_sample_bilinear(tex, tw, th, lut, tu, tv);
+    if (albedo) *albedo = texel;
+    const f3 nl = neg3(normalize3(mk3(1.0f, -1.0f, -5.0f)));  // -normalize(kLightDir), :55
+    float ndl = fmaxf(0.0f, dot3(n, nl));
+    f3 diffuse = scale3(texel, ndl);
+    f3 half_dir = normalize3(sub3(nl, D));
+    float sp = pow32(fmaxf(0.0f, dot3(half_dir, n)));
+    return mk3((ka[0] + diffuse.x) + ks[0] * sp, (ka[1] + diffuse.y) + ks[1] * sp, (ka[2] + diffuse.z) + ks[2] * sp);
+}
+
+// rgba8unorm store conversion: clamp, scale, round half up.
+RWR_DEV uint32_t unorm8(float c)
+{
+    float cc = fminf(fmaxf(c, 0.0f), 1.0f);
+    return (uint32_t)floorf(cc * 255.0f + 0.5f);
+}
+RWR_DEV uint32_t pack_rgba8(float r, float g, float b, float a)
+{
+    return unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | (unorm8(a) << 24);
+}
+
+// Running nearest-hit state of the face loop (compute.wgsl:186-202).
+struct MeshHit {
+    bool have;
+    float t;      // distance
+    float u, v;   // un-normalised edge functions of the winner (compute.wgsl:126,135)
+    float ndotd;  // N . D of the winner (sign decides the normal flip, :140)
+    uint32_t idx; // i_min
+};
+
+// One iteration of the loop: triangleRayIntersect (compute.wgsl:82-148) against a
+// prebaked record, then the selection rule of :198-201.  `T` may live in SGPRs
+// (wave-uniform face) or VGPRs (per-lane face).
+RWR_DEV void intersect_and_select(const TriRecord &T, uint32_t idx, f3 O, f3 D, MeshHit &best)
+{
+    const f3 N = ld3(T.N);
+    float ndotd = dot3(N, D);
+    if (fabsf(ndotd) < kEpsilon) return;
+    float t = -(dot3(N, O) + T.d) / ndotd;
+    if (t < 0.0f) return;
+    f3 P = along(O, t, D);
+    f3 C = cross3(ld3(T.e0), sub3(P, ld3(T.p0)));
+    if (dot3(N, C) < 0.0f) return;
+    C = cross3(ld3(T.e1), sub3(P, ld3(T.p1)));
+    float u = dot3(N, C);
+    if (u < 0.0f) return;
+    C = cross3(ld3(T.e2), sub3(P, ld3(T.p2)));
+    float v = dot3(N, C);
+    if (v < 0.0f) return;
+    // (!min_hit.hit && hit) || (hit && distance < min_hit.distance); callers visit
+    // faces in ascending index order, so ties keep the lowest index.
+    if (!best.have || t < best.t) {
+        best.have = true;
+        best.t = t;
+        best.u = u;
+        best.v = v;
+        best.ndotd = ndotd;
+        best.idx = idx;
+    }
+}
+
+}  // namespace rwr

@@ -1,0 +1,71 @@
+// Internal declarations shared by the HIP kernels and the C-ABI implementation.
+// Not part of the public boundary (include/rwr_hip.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rwr_hip.h"
+
+namespace rwr {
+
+// ---------------------------------------------------------------------------
+// Device-side scene records (data layout in HBM, see DESIGN.md §"Data layout").
+//
+// TriRecord: everything triangleRayIntersect (compute.wgsl:82-148) derives from
+// the triangle alone, hoisted out of the per-ray loop.  The values are produced
+// by k_prebake with exactly the operations the shader writes (no fusion), so
+// hoisting does not change a single bit of the per-ray result.
+// 128 B = four s_load_dwordx8 when the face index is wave-uniform.
+struct alignas(16) TriRecord {
+    float p0[3]; float d;      // d = -dot(N, p0)                      compute.wgsl:99
+    float p1[3]; float denom;  // denom = dot(N, N)                    compute.wgsl:88
+    float p2[3]; float pad0;
+    float N[3];  float pad1;   // cross(p1 - p0, p2 - p0)              compute.wgsl:84-87
+    float e0[3]; float pad2;   // p1 - p0                              compute.wgsl:115
+    float e1[3]; float pad3;   // p2 - p1                              compute.wgsl:123
+    float e2[3]; float pad4;   // p0 - p2                              compute.wgsl:132
+    float pad5[4];
+};
+static_assert(sizeof(TriRecord) == 128, "TriRecord is 128 B");
+
+// Texture coordinates of a face's three corners (compute.wgsl:218-220), 32 B.
+struct alignas(16) FaceUV {
+    float uv0[2], uv1[2], uv2[2];
+    float pad[2];
+};
+static_assert(sizeof(FaceUV) == 32, "FaceUV is 32 B");
+
+struct Targets {
+    uint8_t *color;     // W*H*4 rgba8unorm            (screen_texture, lib.rs:503-515)
+    float *depth;       // W*H r32float                (depth_texture_output, lib.rs:482-495)
+    float *color_f32;   // W*H*4, aux
+    int32_t *obj_id;    // W*H, aux
+    float *hit_t;       // W*H, aux
+};
+
+struct FrameParams {
+    rwr_camera_inv_uniform cam;
+    uint32_t width, height;       // full frame
+    uint32_t row_begin, row_end;  // band rendered by this launch
+    uint32_t n_spheres;
+    uint32_t n_tris;
+    uint32_t tex_w, tex_h;
+    uint32_t flags;
+    uint32_t pad;
+    rwr_sphere_buffer_data spheres[RWR_MAX_SPHERES];
+    float ambient[4];
+    float specular[4];
+};
+
+// context.cpp: records the calling thread's error message, returns `code`.
+int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// kernels_primary.hip
+hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, const rwr_model_face_small *faces,
+                          uint32_t n_faces, const rwr_instance_raw *instances, uint32_t n_instances,
+                          TriRecord *tris, FaceUV *face_uv);
+hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+                          const uint32_t *tex, const float *srgb_lut, const Targets &tg);
+
+}  // namespace rwr
