@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mray/s and ms/frame, suzanne_lowpoly at 1920x1080 (BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame of the reference's render loop (clear + 2 sphere passes +
+mesh pass, /root/reference/src/lib.rs:1024-1184) through the C ABI of
+include/rwr_hip.h.  Scene, camera and targets are resident in HBM before the
+timed region.  With N > 1 the frame is split into N contiguous row bands (one
+process per GPU) and every step ends with ONE RCCL gather of the finished bands
+to rank 0 (north_star) — total work is fixed, so "scaling" is "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     — dominant kernel vs the HBM roof (algorithmic bytes = 8 B/pixel:
+                 RGBA8 + R32F store), duration from HIP events on the
+                 launch stream;
+  cpu_baseline — the CPU oracle (a port of the reference shaders; the reference's
+                 own wgpu/llvmpipe path cannot be built here) timed on the host
+                 cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_PEAK_TFLOPS = 157.3    # vector FP32 spec
+ALGO_BYTES_PER_PIXEL = 8    # 4 B RGBA8 + 4 B R32F depth, each pixel stored once
+
+CONFIGS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "cfg2": dict(scene="suzanne_lowpoly.obj", width=1920, height=1080, spp=1, bounces=0,
+                 camera=dict(eye=(0, 0, 0), target=(0, 0, -1)),
+                 label="suzanne_lowpoly.obj 1920x1080 1spp primary rays, reference camera + 2 spheres (configs[1])"),
+    # the same scene from outside (15 x 'S'): 3 % of the pixels hit the mesh
+    "cfg2b": dict(scene="suzanne_lowpoly.obj", width=1920, height=1080, spp=1, bounces=0,
+                  camera=dict(eye=(0, 0, 3), target=(0, 0, -1)),
+                  label="suzanne_lowpoly.obj 1920x1080 1spp primary rays, eye (0,0,3) + 2 spheres"),
+    "cfg1": dict(scene="cube.obj", width=256, height=256, spp=1, bounces=0,
+                 camera=dict(eye=(0, 0, 0), target=(0, 0, -1)),
+                 label="cube.obj 256x256 1spp primary rays (configs[0])"),
+}
+
+
+def band_rows(rank: int, world: int, height: int) -> tuple[int, int]:
+    """Contiguous row band of `rank`; bands tile [0,height) exactly."""
+    return (rank * height) // world, ((rank + 1) * height) // world
+
+
+class _DevArray:
+    """Zero-copy view of device memory for torch.as_tensor (__cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(cfg, budget_s: float) -> dict:
+    """Times the CPU oracle on whole frames of the same workload (checker code used
+    as the reported CPU baseline, never as the product path)."""
+    from oracle import oracle as orc, ref_loader
+    import __graft_entry__ as graft
+
+    rwr = graft.load_package()
+    model = ref_loader.load_model_compute(rwr.RES_DIR, cfg["scene"])
+    w, h = cfg["width"], cfg["height"]
+    cam_inv = orc.camera_build_inv_uniform(orc.make_camera(aspect=w / h, **cfg["camera"]))
+    screen, spheres = orc.make_screen(w, h), orc.make_spheres()
+    orc.render_frame(cam_inv, screen, spheres, model, want_aux=False)  # warm-up (page in, thread pool)
+    times = []
+    t_start = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        orc.render_frame(cam_inv, screen, spheres, model, want_aux=False)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start >= budget_s or len(times) >= 64:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": round(w * h / med / 1e6, 3), "unit": "Mray/s", "cores": orc.num_threads(), "kind": "port",
+        "ms_per_frame": round(med * 1e3, 2),
+        "sample": f"{len(times)} full {w}x{h} frames of the same workload (median), brute-force per-pixel loop as in the WGSL, "
+                  f"gcc -O2 + OpenMP rows; reference wgpu/llvmpipe path not buildable here (no Rust toolchain, no Vulkan ICD)",
+    }
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    import torch
+    import __graft_entry__ as graft
+
+    rwr = graft.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            return 2
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the render path has no CPU fallback", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # backend "nccl" is RCCL on ROCm
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    w, h = cfg["width"], cfg["height"]
+    r0, r1 = band_rows(rank, world, h)
+    model = rwr.load_model_compute(cfg["scene"])
+    cam_inv = rwr.camera_build_inv_uniform(rwr.make_camera(aspect=w / h, **cfg["camera"]))
+    params = rwr.make_params(spp=cfg["spp"], max_bounces=cfg["bounces"])
+
+    ctx = rwr.Context(local_rank)
+    info = ctx.device_info()
+    ctx.upload_model(model)
+    ctx.set_spheres(rwr.make_spheres())
+    ctx.resize(w, h)
+    # A dedicated (non-null) torch stream carries the kernels, the RCCL gather and the
+    # timing events, so HIP events bracket exactly the launches of the timed region.
+    stream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ctx.set_stream(stream.cuda_stream)
+
+    band = None
+    gather_list = None
+    if world > 1:
+        d_color, _ = ctx.device_targets()
+        band = torch.as_tensor(_DevArray(d_color + r0 * w * 4, (r1 - r0) * w * 4), device=f"cuda:{local_rank}")
+        if rank == 0:
+            frame = torch.empty(h * w * 4, dtype=torch.uint8, device=f"cuda:{local_rank}")
+            gather_list = []
+            for rr in range(world):
+                a, b = band_rows(rr, world, h)
+                gather_list.append(frame[a * w * 4:b * w * 4])
+
+    render = ctx.render_call(cam_inv, params, (r0, r1))
+
+    def step():
+        render()
+        if world > 1:
+            dist.gather(band, gather_list, dst=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+
+    # timed region: exactly K steps; HIP events on the launch stream for the kernel time
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    dev_ms = ev0.elapsed_time(ev1)
+
+    if world > 1:
+        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = float(t[0]), float(t[1])
+
+    rays_per_frame = w * h * cfg["spp"] * (1 + cfg["bounces"])
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = rays_per_frame / (elapsed / args.steps) / 1e6
+
+    out = None
+    if rank == 0:
+        # dominant kernel: k_primary — one launch per step on this rank's band
+        launch_s = dev_ms * 1e-3 / args.steps
+        algo_bytes = ALGO_BYTES_PER_PIXEL * w * (r1 - r0)
+        achieved = algo_bytes / launch_s / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "k_primary", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(launch_s * 1e6, 3),
+            "note": "8 B/pixel stores only; the kernel is VALU/latency-bound at this scene size (DESIGN.md)",
+        }
+        out = {
+            "metric": "Mray/s", "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "ms_per_frame": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["label"], "width": w, "height": h, "spp": cfg["spp"], "bounces": cfg["bounces"],
+                       "faces": int(len(model["faces"])), "partition": f"{world} row band(s) + 1 RCCL gather" if world > 1 else "single GPU",
+                       "device": info["name"]},
+            "roofline": roofline,
+        }
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -270,6 +270,20 @@ class Context:
         else:
             _check(lib().rwr_render_rows(self._h, _p(cam_inv), _p(params), rows[0], rows[1]))
 
+    def render_call(self, cam_inv, params, rows):
+        """A zero-argument callable that enqueues one frame; arguments are marshalled
+        once so that the per-frame host cost is one foreign call."""
+        fn, h = lib().rwr_render_rows, self._h
+        a, b = _p(cam_inv), _p(params)
+        r0, r1 = C.c_uint32(rows[0]), C.c_uint32(rows[1])
+
+        def call(_keep=(cam_inv, params)):
+            rc = fn(h, a, b, r0, r1)
+            if rc:
+                _check(rc)
+
+        return call
+
     def synchronize(self):
         _check(lib().rwr_synchronize(self._h))
 

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -73,6 +74,8 @@ struct rwr_context {
     DeviceBuffer<rwr_instance_raw> d_instances;
     DeviceBuffer<TriRecord> d_tris;
     DeviceBuffer<FaceUV> d_face_uv;
+    DeviceBuffer<CullRec> d_cull;
+    DeviceBuffer<FrameTri> d_ftris;
     DeviceBuffer<uint32_t> d_tex;
     DeviceBuffer<float> d_lut;
     uint32_t n_verts = 0, n_faces = 0, n_instances = 0, n_tris = 0;
@@ -93,6 +96,7 @@ struct rwr_context {
     bool aux_valid = false;
 
     uint64_t last_primary = 0, last_bounce = 0;
+    uint32_t wave_cull_min = 4;  // tunable: RWR_WAVE_CULL_MIN
 };
 
 namespace {
@@ -121,14 +125,72 @@ void build_srgb_lut(float *lut)
     }
 }
 
+// Per-frame culling constants (rwr_internal.h CullConsts), evaluated in double.
+void compute_cull_consts(const rwr_camera_inv_uniform &cam, uint32_t width, uint32_t height, CullConsts &cc)
+{
+    auto dir = [&](double fx, double fy, double out[3]) {
+        const double xn = 2.0 * fx / (double)width - 1.0, yn = 2.0 * fy / (double)height - 1.0;
+        double v[4];
+        for (int r = 0; r < 4; r++)
+            v[r] = cam.proj_inv[0][r] * xn + cam.proj_inv[1][r] * yn + cam.proj_inv[2][r] + cam.proj_inv[3][r];
+        for (int r = 0; r < 3; r++)
+            out[r] = cam.viewmodel_inv[0][r] * v[0] + cam.viewmodel_inv[1][r] * v[1] + cam.viewmodel_inv[2][r] * v[2];
+    };
+    auto cross = [](const double a[3], const double b[3], double o[3]) {
+        o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    double A[3], Px[3], Py[3], Bx[3], By[3];
+    dir(0.0, 0.0, A);
+    dir((double)width, 0.0, Px);
+    dir(0.0, (double)height, Py);
+    for (int k = 0; k < 3; k++) { Bx[k] = (Px[k] - A[k]) / (double)width; By[k] = (Py[k] - A[k]) / (double)height; }
+    double Ux[3], Vx[3], Uy[3], Vy[3];
+    cross(A, By, Ux); cross(Bx, By, Vx);
+    cross(A, Bx, Uy); cross(By, Bx, Vy);
+    const double detx = Ux[0] * Bx[0] + Ux[1] * Bx[1] + Ux[2] * Bx[2];  // n_x . Bx
+    const double dety = Uy[0] * By[0] + Uy[1] * By[1] + Uy[2] * By[2];  // n_y . By
+    const double sx = detx < 0.0 ? -1.0 : 1.0, sy = dety < 0.0 ? -1.0 : 1.0;
+    std::memset(&cc, 0, sizeof cc);
+    double l1[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 3; k++) {
+        cc.A[k] = (float)A[k]; cc.Bx[k] = (float)Bx[k]; cc.By[k] = (float)By[k];
+        cc.Ux[k] = (float)(sx * Ux[k]); cc.Vx[k] = (float)(sx * Vx[k]);
+        cc.Uy[k] = (float)(sy * Uy[k]); cc.Vy[k] = (float)(sy * Vy[k]);
+        l1[0] += std::fabs(Ux[k]); l1[1] += std::fabs(Vx[k]); l1[2] += std::fabs(Uy[k]); l1[3] += std::fabs(Vy[k]);
+    }
+    cc.Ux[3] = (float)l1[0]; cc.Vx[3] = (float)l1[1]; cc.Uy[3] = (float)l1[2]; cc.Vy[3] = (float)l1[3];
+    for (int k = 0; k < 3; k++) cc.origin[k] = cam.origin[k];
+    // the largest |dir|_1 (dir is affine, so |dir|_1 peaks at a screen corner)
+    double corner[4][3];
+    dir(0.0, 0.0, corner[0]); dir((double)width, 0.0, corner[1]);
+    dir((double)width, (double)height, corner[2]); dir(0.0, (double)height, corner[3]);
+    double max_dir_l1 = 0.0;
+    for (int c = 0; c < 4; c++)
+        max_dir_l1 = std::fmax(max_dir_l1, std::fabs(corner[c][0]) + std::fabs(corner[c][1]) + std::fabs(corner[c][2]));
+    const double k_rel = 2e-5;  // kCullRel (rwr_cull.h)
+    cc.corner_margin = (float)(k_rel * 1.001 * max_dir_l1);
+    double vxa = 0.0, vya = 0.0;
+    for (int k = 0; k < 3; k++) { vxa += sx * Vx[k] * A[k]; vya += sy * Vy[k] * A[k]; }
+    cc.vxa = (float)vxa; cc.vya = (float)vya;
+    // a pinhole camera has both determinants well away from 0; a singular or non-finite
+    // uniform simply disables culling (the exact test then sees every face)
+    const double bx1 = std::fabs(Bx[0]) + std::fabs(Bx[1]) + std::fabs(Bx[2]);
+    const double by1 = std::fabs(By[0]) + std::fabs(By[1]) + std::fabs(By[2]);
+    const bool ok = std::isfinite(detx) && std::isfinite(dety) && std::isfinite(max_dir_l1) &&
+                    std::fabs(detx) > 1e-9 * l1[0] * bx1 && std::fabs(dety) > 1e-9 * l1[2] * by1;
+    cc.enabled = (ok && cc.vxa != 0.0f && cc.vya != 0.0f) ? 1u : 0u;
+}
+
 int rebuild_tris(rwr_context *ctx)
 {
     if (!ctx->tris_dirty) return RWR_OK;
     const uint32_t total = ctx->n_faces * (ctx->n_instances ? ctx->n_instances : 1u);
     RWR_HIP_CHECK(ctx->d_tris.ensure(total));
     RWR_HIP_CHECK(ctx->d_face_uv.ensure(total));
+    RWR_HIP_CHECK(ctx->d_cull.ensure(total));
+    RWR_HIP_CHECK(ctx->d_ftris.ensure(total));
     RWR_HIP_CHECK(launch_prebake(ctx->stream, ctx->d_verts.ptr, ctx->d_faces.ptr, ctx->n_faces, ctx->d_instances.ptr,
-                                 ctx->n_instances, ctx->d_tris.ptr, ctx->d_face_uv.ptr));
+                                 ctx->n_instances, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_cull.ptr));
     ctx->n_tris = total;
     ctx->tris_dirty = false;
     return RWR_OK;
@@ -177,6 +239,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
         return set_error(RWR_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
     }
     ctx->stream = ctx->own_stream;
+    if (const char *e2 = std::getenv("RWR_WAVE_CULL_MIN")) ctx->wave_cull_min = (uint32_t)std::strtoul(e2, nullptr, 10);
     float lut[256];
     build_srgb_lut(lut);
     if ((e = ctx->d_lut.ensure(256)) != hipSuccess ||
@@ -194,7 +257,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
     DeviceGuard g(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
-    ctx->d_tris.release(); ctx->d_face_uv.release(); ctx->d_tex.release(); ctx->d_lut.release();
+    ctx->d_tris.release(); ctx->d_face_uv.release(); ctx->d_cull.release(); ctx->d_ftris.release(); ctx->d_tex.release(); ctx->d_lut.release();
     ctx->d_color.release(); ctx->d_depth.release(); ctx->d_color_f32.release();
     ctx->d_obj_id.release(); ctx->d_hit_t.release();
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -349,6 +412,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
 
     FrameParams fp{};
     fp.cam = *camera;
+    fp.wave_cull_min = ctx->wave_cull_min;
     fp.width = ctx->screen.width;
     fp.height = ctx->screen.height;
     fp.row_begin = row_begin;
@@ -365,7 +429,13 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     }
     Targets tg{ctx->d_color.ptr, ctx->d_depth.ptr, aux ? ctx->d_color_f32.ptr : nullptr,
                aux ? ctx->d_obj_id.ptr : nullptr, aux ? ctx->d_hit_t.ptr : nullptr};
-    RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_tex.ptr, ctx->d_lut.ptr, tg));
+    if (ctx->n_tris && !(rp.flags & RWR_FLAG_NO_CULL)) {
+        // per-frame, per-face culling records (depends on the camera: runs every frame)
+        CullConsts cc;
+        compute_cull_consts(*camera, ctx->screen.width, ctx->screen.height, cc);
+        RWR_HIP_CHECK(launch_frame_setup(ctx->stream, cc, ctx->d_cull.ptr, ctx->n_tris, ctx->d_ftris.ptr));
+    }
+    RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, ctx->d_lut.ptr, tg));
     ctx->aux_valid = aux;
     ctx->last_primary = (uint64_t)ctx->screen.width * (row_end - row_begin);
     ctx->last_bounce = 0;

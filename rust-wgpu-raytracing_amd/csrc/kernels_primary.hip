@@ -12,14 +12,18 @@
 //    "clear" is the miss value of the same store.
 //  * depth compositing between the passes lives in registers; the depth
 //    ping-pong textures and their copies disappear.
-//  * per wave, lanes first test 64 faces at a time against the tile's ray
-//    frustum (all primary rays share the camera origin), __ballot the
-//    survivors, and the wave then walks the set bits in ascending face order:
-//    the face index is wave-uniform, so its 128-byte TriRecord arrives through
-//    scalar loads and sits in SGPRs while 64 rays are tested against it.
+//  * all primary rays share the camera origin, so faces are culled against ray
+//    frusta, two levels deep: the workgroup's 256 threads test 256 faces at a
+//    time against the 32x8 block frustum and compact the survivors (ballot +
+//    prefix popcount, order-preserving) into an LDS candidate list; each wave
+//    then tests the list entries, one per lane, against its own 8x8 tile
+//    frustum, __ballots again and walks the set bits in ascending face order.
+//    The face index is wave-uniform there, so its 128-byte TriRecord arrives
+//    through scalar loads and sits in SGPRs while 64 rays are tested against it.
 //    Ascending order + strict '<' reproduces the reference's lowest-index tie
 //    rule; skipped faces are ones no ray of the tile can hit, so the result is
 //    bit-identical to the brute-force loop (checked against RWR_FLAG_NO_CULL).
+#include "rwr_cull.h"
 #include "rwr_device.h"
 
 namespace rwr {
@@ -30,7 +34,7 @@ namespace rwr {
 __global__ void __launch_bounds__(256)
 k_prebake(const rwr_model_vertex_small *__restrict__ verts, const rwr_model_face_small *__restrict__ faces,
           uint32_t n_faces, const rwr_instance_raw *__restrict__ instances, uint32_t n_instances,
-          TriRecord *__restrict__ tris, FaceUV *__restrict__ face_uv)
+          TriRecord *__restrict__ tris, FaceUV *__restrict__ face_uv, CullRec *__restrict__ cull)
 {
     const uint32_t total = n_faces * (n_instances ? n_instances : 1u);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,79 +73,68 @@ k_prebake(const rwr_model_vertex_small *__restrict__ verts, const rwr_model_face
     U.uv2[0] = v2.tex_coords[0]; U.uv2[1] = v2.tex_coords[1];
     U.pad[0] = U.pad[1] = 0.0f;
     face_uv[i] = U;
+    CullRec R;
+    R.p0[0] = p0.x; R.p0[1] = p0.y; R.p0[2] = p0.z;
+    R.p1[0] = p1.x; R.p1[1] = p1.y; R.p1[2] = p1.z;
+    R.p2[0] = p2.x; R.p2[1] = p2.y; R.p2[2] = p2.z;
+    R.pad[0] = R.pad[1] = R.pad[2] = 0.0f;
+    cull[i] = R;
 }
 
 hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, const rwr_model_face_small *faces,
                           uint32_t n_faces, const rwr_instance_raw *instances, uint32_t n_instances,
-                          TriRecord *tris, FaceUV *face_uv)
+                          TriRecord *tris, FaceUV *face_uv, CullRec *cull)
 {
     const uint32_t total = n_faces * (n_instances ? n_instances : 1u);
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(k_prebake, dim3((total + 255) / 256), dim3(256), 0, s, verts, faces, n_faces, instances,
-                       n_instances, tris, face_uv);
+                       n_instances, tris, face_uv, cull);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
-// Tile frustum: the four side planes (through the shared ray origin) of the
-// pyramid spanned by an 8x8 pixel tile.  Normals point inward.
-struct TileFrustum {
-    f3 n[4];
-    float l1[4];  // |n|_1, for the rounding margin
-};
-
-RWR_DEV TileFrustum make_tile_frustum(const rwr_camera_inv_uniform &cam, float x0, float y0, float x1, float y1,
-                                      float width, float height)
+// Per-frame culling records: one thread per face (rwr_cull.h).
+__global__ void __launch_bounds__(256)
+k_frame_setup(const CullConsts cc, const CullRec *__restrict__ cull, uint32_t n_tris, FrameTri *__restrict__ ftris)
 {
-    const f3 c00 = ray_dir_unnormalized(cam, x0, y0, width, height);
-    const f3 c10 = ray_dir_unnormalized(cam, x1, y0, width, height);
-    const f3 c11 = ray_dir_unnormalized(cam, x1, y1, width, height);
-    const f3 c01 = ray_dir_unnormalized(cam, x0, y1, width, height);
-    const f3 mid = ray_dir_unnormalized(cam, 0.5f * (x0 + x1), 0.5f * (y0 + y1), width, height);
-    TileFrustum fr;
-    fr.n[0] = cross3(c00, c10);
-    fr.n[1] = cross3(c10, c11);
-    fr.n[2] = cross3(c11, c01);
-    fr.n[3] = cross3(c01, c00);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (dot3(fr.n[k], mid) < 0.0f) fr.n[k] = neg3(fr.n[k]);
-        fr.l1[k] = fabsf(fr.n[k].x) + fabsf(fr.n[k].y) + fabsf(fr.n[k].z);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tris) return;
+    FrameTri T;
+    if (cc.enabled) {
+        T = make_frame_tri(cc, cull[i]);
+    } else {
+        const float inf = __builtin_inff();
+        T.bx0 = -inf; T.by0 = -inf; T.bx1 = inf; T.by1 = inf;
+        T.ea[0] = T.ea[1] = T.ea[2] = inf;
+        T.ex[0] = T.ex[1] = T.ex[2] = 0.0f;
+        T.ey[0] = T.ey[1] = T.ey[2] = 0.0f;
+        T.me0 = T.me1 = T.me2 = 0.0f;
     }
-    return fr;
+    ftris[i] = T;
 }
 
-// True when the triangle lies entirely outside one side plane, with a margin
-// (relative 2e-5 on L1 norms, >100x the f32 rounding of the hit test) so that no
-// face the exact test could accept for a ray inside the tile is ever dropped.
-// NaNs compare false => "keep".
-RWR_DEV bool tile_culls_triangle(const TileFrustum &fr, f3 q0, f3 q1, f3 q2)
+hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const CullRec *cull, uint32_t n_tris, FrameTri *ftris)
 {
-    constexpr float kRel = 2e-5f;
-    const float m0 = kRel * (fabsf(q0.x) + fabsf(q0.y) + fabsf(q0.z));
-    const float m1 = kRel * (fabsf(q1.x) + fabsf(q1.y) + fabsf(q1.z));
-    const float m2 = kRel * (fabsf(q2.x) + fabsf(q2.y) + fabsf(q2.z));
-    bool culled = false;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float s0 = dot3(fr.n[k], q0), s1 = dot3(fr.n[k], q1), s2 = dot3(fr.n[k], q2);
-        culled |= (s0 < -m0 * fr.l1[k]) && (s1 < -m1 * fr.l1[k]) && (s2 < -m2 * fr.l1[k]);
-    }
-    return culled;
+    if (n_tris == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_frame_setup, dim3((n_tris + 255) / 256), dim3(256), 0, s, cc, cull, n_tris, ftris);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
 template <bool AUX, bool CULL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 8)  // 8 waves per SIMD: <= 64 VGPRs
 k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
-          const uint32_t *__restrict__ tex, const float *__restrict__ srgb_lut, const Targets tg)
+          const FrameTri *__restrict__ ftris, const uint32_t *__restrict__ tex, const float *__restrict__ srgb_lut,
+          const Targets tg)
 {
     __shared__ float s_lut[256];
+    __shared__ uint32_t s_cand[256];   // block-level candidate faces of the current batch, ascending
+    __shared__ uint32_t s_wave_cnt[4];
     s_lut[threadIdx.x] = srgb_lut[threadIdx.x];
-    __syncthreads();
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t tile_x0 = blockIdx.x * 32u + wave * 8u;
+    const uint32_t blk_x0 = blockIdx.x * 32u;
+    const uint32_t tile_x0 = blk_x0 + wave * 8u;
     const uint32_t tile_y0 = p.row_begin + blockIdx.y * 8u;
     const uint32_t px = tile_x0 + (lane & 7u), py = tile_y0 + (lane >> 3);
     const bool in_range = (px < p.width) && (py < p.row_end);
@@ -150,7 +143,7 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV 
     const f3 D = pixel_to_ray_dir(p.cam, px, py, 0.5f, 0.5f, p.width, p.height);
 
     // Framebuffer state of this pixel, as the reference's cleared textures hold it.
-    float depth_tex = 0.0f;                       // depth_texture_* after the clear (lib.rs:1024-1104)
+    float depth_tex = 0.0f;                            // depth_texture_* after the clear (lib.rs:1024-1104)
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;  // screen_texture after the clear
     int32_t obj = -1;
     float hit_t = 0.0f;
@@ -175,28 +168,54 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV 
     // -- mesh pass (lib.rs:1174-1184) -----------------------------------------
     MeshHit best;
     best.have = false; best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.ndotd = 0.0f; best.idx = 0u;
+    uint32_t dbg_tested = 0, dbg_listed = 0;  // RWR_FLAG_DEBUG_COUNTS (aux builds only)
 
     if (p.n_tris) {
-        TileFrustum fr;
-        if (CULL) {
-            const float fx0 = (float)tile_x0, fy0 = (float)tile_y0;
-            fr = make_tile_frustum(p.cam, fx0, fy0, fx0 + 8.0f, fy0 + 8.0f, (float)p.width, (float)p.height);
-        }
-        for (uint32_t base = 0; base < p.n_tris; base += 64u) {
-            const uint32_t j = base + lane;
+        const bool cull_on = CULL;
+        const float by0 = (float)tile_y0, bx0 = (float)blk_x0, tx0 = (float)tile_x0;
+        const TileRect blk_rect = {bx0, by0, bx0 + 32.0f, by0 + 8.0f};
+        const TileRect tile_rect = {tx0, by0, tx0 + 8.0f, by0 + 8.0f};
+        for (uint32_t base = 0; base < p.n_tris; base += 256u) {
+            // level 1: 256 faces vs the block frustum, order-preserving compaction into LDS
+            const uint32_t j = base + threadIdx.x;
             bool keep = j < p.n_tris;
-            if (CULL && keep) {
-                const TriRecord &T = tris[j];
-                keep = !tile_culls_triangle(fr, sub3(ld3(T.p0), O), sub3(ld3(T.p1), O), sub3(ld3(T.p2), O));
+            if (cull_on && keep) keep = !rect_culls(ftris[j], blk_rect);
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t off = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) {
+                const uint32_t c = s_wave_cnt[w];
+                off += (w < wave) ? c : 0u;
+                total += c;
             }
-            unsigned long long mask = __ballot(keep);
-            while (mask) {
-                const uint32_t b = (uint32_t)__builtin_ctzll(mask);
-                mask &= mask - 1ull;
-                const uint32_t idx = base + b;  // wave-uniform: record comes in through scalar loads
-                intersect_and_select(tris[idx], idx, O, D, best);
+            total = __builtin_amdgcn_readfirstlane(total);
+            if (AUX) dbg_listed += total;
+            if (keep) s_cand[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
+            __syncthreads();
+            // level 2: list entries vs this wave's tile frustum (skipped for short lists,
+            // where it costs more than the exact tests it saves), then the exact test
+            const bool wave_cull = cull_on && total > p.wave_cull_min;
+            for (uint32_t cbase = 0; cbase < total; cbase += 64u) {
+                const uint32_t e = cbase + lane;
+                bool keep2 = e < total;
+                const uint32_t my_idx = keep2 ? s_cand[e] : 0u;
+                if (wave_cull && keep2) keep2 = !rect_culls(ftris[my_idx], tile_rect);
+                unsigned long long m2 = __ballot(keep2);
+                while (m2) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(m2);
+                    m2 &= m2 - 1ull;
+                    // wave-uniform face index: the record comes in through scalar loads
+                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_idx, (int)b);
+                    intersect_and_select(tris[idx], idx, O, D, best);
+                    if (AUX) dbg_tested++;
+                }
             }
+            if (base + 256u < p.n_tris) __syncthreads();  // s_cand / s_wave_cnt are rewritten by the next batch
         }
+    } else {
+        __syncthreads();  // s_lut
     }
 
     if (best.have) {
@@ -206,10 +225,8 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV 
             const TriRecord &T = tris[best.idx];
             f3 N = ld3(T.N);
             if (best.ndotd > 0.0f) N = neg3(N);          // compute.wgsl:140-142
-            const float u = best.u / T.denom, v = best.v / T.denom;
-            const f3 n = normalize3(N);
-            const f3 c = shade_mesh(face_uv[best.idx], u, v, 1.0f - u - v, n, D, p.ambient, p.specular, tex, p.tex_w,
-                                    p.tex_h, s_lut, nullptr);
+            const f3 c = shade_mesh(face_uv[best.idx], best.u, best.v, T.denom, N, D, p.ambient, p.specular, tex,
+                                    p.tex_w, p.tex_h, s_lut, nullptr);
             cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
             depth_tex = 1.0f - depth;
             obj = (int32_t)best.idx;
@@ -223,24 +240,25 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV 
         tg.depth[o] = depth_tex;
         if (AUX) {
             reinterpret_cast<float4 *>(tg.color_f32)[o] = make_float4(cr, cg, cb, ca);
-            tg.obj_id[o] = obj;
-            tg.hit_t[o] = hit_t;
+            const bool dbg = (p.flags & RWR_FLAG_DEBUG_COUNTS) != 0;
+            tg.obj_id[o] = dbg ? (int32_t)dbg_listed : obj;
+            tg.hit_t[o] = dbg ? (float)dbg_tested : hit_t;
         }
     }
 }
 
 hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
-                          const uint32_t *tex, const float *srgb_lut, const Targets &tg)
+                          const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
     const dim3 grid((fp.width + 31u) / 32u, (fp.row_end - fp.row_begin + 7u) / 8u);
     const dim3 block(256);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
-    const bool cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
-    if (aux && cull) hipLaunchKernelGGL((k_primary<true, true>), grid, block, 0, s, fp, tris, face_uv, tex, srgb_lut, tg);
-    else if (aux) hipLaunchKernelGGL((k_primary<true, false>), grid, block, 0, s, fp, tris, face_uv, tex, srgb_lut, tg);
-    else if (cull) hipLaunchKernelGGL((k_primary<false, true>), grid, block, 0, s, fp, tris, face_uv, tex, srgb_lut, tg);
-    else hipLaunchKernelGGL((k_primary<false, false>), grid, block, 0, s, fp, tris, face_uv, tex, srgb_lut, tg);
+    const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
+    if (aux && do_cull) hipLaunchKernelGGL((k_primary<true, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
+    else if (aux) hipLaunchKernelGGL((k_primary<true, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
+    else if (do_cull) hipLaunchKernelGGL((k_primary<false, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
+    else hipLaunchKernelGGL((k_primary<false, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
     return hipGetLastError();
 }
 

@@ -83,7 +83,15 @@ RWR_DEV f3 pixel_to_ray_dir(const rwr_camera_inv_uniform &cam, uint32_t x, uint3
     return normalize3(ray_dir_unnormalized(cam, (float)x + jx, (float)y + jy, (float)width, (float)height));
 }
 
-// sphereRayIntersect, sphere/compute.wgsl:63-85.  Returns hit; t and normal on hit.
+// FMA dot product and hardware-rsq normalisation for the colour path only.
+RWR_DEV float cdot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+RWR_DEV f3 cnormalize(f3 a)
+{
+    const float r = __builtin_amdgcn_rsqf(cdot(a, a));
+    return mk3(a.x * r, a.y * r, a.z * r);
+}
+
+// sphereRayIntersect, sphere/compute.wgsl:63-85 (the normal feeds only the colour).  Returns hit; t and normal on hit.
 RWR_DEV bool sphere_ray_intersect(f3 center, float radius, f3 O, f3 D, float &t_out, f3 &n_out)
 {
     f3 oc = sub3(O, center);
@@ -100,7 +108,7 @@ RWR_DEV bool sphere_ray_intersect(f3 center, float radius, f3 O, f3 D, float &t_
     else if (t2 >= 0.0f) t = t2;
     else return false;
     f3 P = along(O, t, D);
-    n_out = normalize3(sub3(P, center));
+    n_out = cnormalize(sub3(P, center));
     t_out = t;
     return true;
 }
@@ -116,10 +124,10 @@ RWR_DEV float pow32(float x)
 // Sphere shading, sphere/compute.wgsl:137-152.
 RWR_DEV f3 shade_sphere(f3 n, f3 D)
 {
-    const f3 nl = neg3(normalize3(mk3(1.0f, -5.0f, 1.0f)));  // -normalize(kLightDir), :41
-    float diffuse = 1.0f * fmaxf(0.0f, dot3(n, nl));
-    f3 half_dir = normalize3(sub3(nl, D));
-    float specular = 0.5f * pow32(fmaxf(0.0f, dot3(half_dir, n)));
+    const f3 nl = neg3(normalize3(mk3(1.0f, -5.0f, 1.0f)));  // -normalize(kLightDir), :41 (folded at compile time)
+    float diffuse = 1.0f * fmaxf(0.0f, cdot(n, nl));
+    f3 half_dir = cnormalize(sub3(nl, D));
+    float specular = 0.5f * pow32(fmaxf(0.0f, cdot(half_dir, n)));
     float k = 0.1f + diffuse;
     return mk3(k * 1.0f + specular, k * 0.0f + specular, k * 0.0f + specular);
 }
@@ -143,30 +151,35 @@ RWR_DEV f3 tex_sample_bilinear(const uint32_t *__restrict__ tex, uint32_t tw, ui
     uint32_t t01 = tex[y1 * tw + x0], t11 = tex[y1 * tw + x1];
     float w00 = (1.0f - ax) * (1.0f - ay), w10 = ax * (1.0f - ay);
     float w01 = (1.0f - ax) * ay, w11 = ax * ay;
-    f3 c;
-    c.x = lut[t00 & 255u] * w00 + lut[t10 & 255u] * w10 + lut[t01 & 255u] * w01 + lut[t11 & 255u] * w11;
-    c.y = lut[(t00 >> 8) & 255u] * w00 + lut[(t10 >> 8) & 255u] * w10 + lut[(t01 >> 8) & 255u] * w01 +
-          lut[(t11 >> 8) & 255u] * w11;
-    c.z = lut[(t00 >> 16) & 255u] * w00 + lut[(t10 >> 16) & 255u] * w10 + lut[(t01 >> 16) & 255u] * w01 +
-          lut[(t11 >> 16) & 255u] * w11;
-    return c;
+    auto mix = [&](uint32_t sh) {
+        return __builtin_fmaf(lut[(t11 >> sh) & 255u], w11,
+               __builtin_fmaf(lut[(t01 >> sh) & 255u], w01,
+               __builtin_fmaf(lut[(t10 >> sh) & 255u], w10, lut[(t00 >> sh) & 255u] * w00)));
+    };
+    return mk3(mix(0u), mix(8u), mix(16u));
 }
 
-// Mesh shading, triangle_list/compute.wgsl:217-234.  bary = (u, v, 1-u-v) weights
-// of (p0,p1,p2); n is the facing unit normal.  *albedo receives the texel.
-RWR_DEV f3 shade_mesh(const FaceUV &fuv, float b0, float b1, float b2, f3 n, f3 D, const float *ka, const float *ks,
-                      const uint32_t *__restrict__ tex, uint32_t tw, uint32_t th, const float *lut, f3 *albedo)
+// Mesh shading, triangle_list/compute.wgsl:217-234 (colour path: see the header).
+// (eu, ev) are the winner's un-normalised edge functions, denom = dot(N, N);
+// N_facing the face normal already flipped towards the ray (compute.wgsl:140-147).
+// *albedo receives the filtered texel.
+RWR_DEV f3 shade_mesh(const FaceUV &fuv, float eu, float ev, float denom, f3 N_facing, f3 D, const float *ka,
+                      const float *ks, const uint32_t *__restrict__ tex, uint32_t tw, uint32_t th, const float *lut,
+                      f3 *albedo)
 {
-    float tu = b0 * fuv.uv0[0] + b1 * fuv.uv1[0] + b2 * fuv.uv2[0];
-    float tv = b0 * fuv.uv0[1] + b1 * fuv.uv1[1] + b2 * fuv.uv2[1];
+    const float rden = __builtin_amdgcn_rcpf(denom);
+    const float b0 = eu * rden, b1 = ev * rden, b2 = 1.0f - b0 - b1;   // barycentric (u, v, 1-u-v), :144-147
+    const f3 n = cnormalize(N_facing);
+    float tu = __builtin_fmaf(b2, fuv.uv2[0], __builtin_fmaf(b1, fuv.uv1[0], b0 * fuv.uv0[0]));
+    float tv = __builtin_fmaf(b2, fuv.uv2[1], __builtin_fmaf(b1, fuv.uv1[1], b0 * fuv.uv0[1]));
     tv = 1.0f - tv;
     f3 texel = tex_sample_bilinear(tex, tw, th, lut, tu, tv);
     if (albedo) *albedo = texel;
-    const f3 nl = neg3(normalize3(mk3(1.0f, -1.0f, -5.0f)));  // -normalize(kLightDir), :55
-    float ndl = fmaxf(0.0f, dot3(n, nl));
+    const f3 nl = neg3(normalize3(mk3(1.0f, -1.0f, -5.0f)));  // -normalize(kLightDir), :55 (folded at compile time)
+    float ndl = fmaxf(0.0f, cdot(n, nl));
     f3 diffuse = scale3(texel, ndl);
-    f3 half_dir = normalize3(sub3(nl, D));
-    float sp = pow32(fmaxf(0.0f, dot3(half_dir, n)));
+    f3 half_dir = cnormalize(sub3(nl, D));
+    float sp = pow32(fmaxf(0.0f, cdot(half_dir, n)));
     return mk3((ka[0] + diffuse.x) + ks[0] * sp, (ka[1] + diffuse.y) + ks[1] * sp, (ka[2] + diffuse.z) + ks[2] * sp);
 }
 
@@ -191,27 +204,31 @@ struct MeshHit {
 };
 
 // One iteration of the loop: triangleRayIntersect (compute.wgsl:82-148) against a
-// prebaked record, then the selection rule of :198-201.  `T` may live in SGPRs
-// (wave-uniform face) or VGPRs (per-lane face).
+// prebaked record, then the selection rule of :198-201.  Written branch-free:
+// every early `return kNoHit` of the shader becomes a term of `hit`, with the
+// same comparison sense (a NaN never rejects, exactly as `x < 0.0` in WGSL), so
+// the accepted set is identical while the whole record is fetched up front and
+// 64 rays proceed in lock-step.  `T` may live in SGPRs (wave-uniform face) or
+// VGPRs (per-lane face).
 RWR_DEV void intersect_and_select(const TriRecord &T, uint32_t idx, f3 O, f3 D, MeshHit &best)
 {
     const f3 N = ld3(T.N);
-    float ndotd = dot3(N, D);
-    if (fabsf(ndotd) < kEpsilon) return;
-    float t = -(dot3(N, O) + T.d) / ndotd;
-    if (t < 0.0f) return;
-    f3 P = along(O, t, D);
-    f3 C = cross3(ld3(T.e0), sub3(P, ld3(T.p0)));
-    if (dot3(N, C) < 0.0f) return;
-    C = cross3(ld3(T.e1), sub3(P, ld3(T.p1)));
-    float u = dot3(N, C);
-    if (u < 0.0f) return;
-    C = cross3(ld3(T.e2), sub3(P, ld3(T.p2)));
-    float v = dot3(N, C);
-    if (v < 0.0f) return;
-    // (!min_hit.hit && hit) || (hit && distance < min_hit.distance); callers visit
-    // faces in ascending index order, so ties keep the lowest index.
-    if (!best.have || t < best.t) {
+    const float ndotd = dot3(N, D);
+    bool hit = !(fabsf(ndotd) < kEpsilon);              // :94
+    const float t = -(dot3(N, O) + T.d) / ndotd;        // :99-102
+    hit &= !(t < 0.0f);                                 // :105
+    const f3 P = along(O, t, D);                        // :110
+    f3 C = cross3(ld3(T.e0), sub3(P, ld3(T.p0)));       // :115-117
+    hit &= !(dot3(N, C) < 0.0f);                        // :118
+    C = cross3(ld3(T.e1), sub3(P, ld3(T.p1)));          // :123-125
+    const float u = dot3(N, C);
+    hit &= !(u < 0.0f);                                 // :127
+    C = cross3(ld3(T.e2), sub3(P, ld3(T.p2)));          // :132-134
+    const float v = dot3(N, C);
+    hit &= !(v < 0.0f);                                 // :136
+    // (!min_hit.hit && hit) || (hit && distance < min_hit.distance), :198; callers
+    // visit faces in ascending index order, so ties keep the lowest index.
+    if (hit && (!best.have || t < best.t)) {
         best.have = true;
         best.t = t;
         best.u = u;

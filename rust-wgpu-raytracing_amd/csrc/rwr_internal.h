@@ -9,6 +9,11 @@
 
 namespace rwr {
 
+// Internal debug flag (not in the public header): with RWR_FLAG_AUX_OUTPUTS, the
+// obj_id plane receives the number of block-level candidate faces and the hit_t
+// plane the number of faces the pixel's wave ran the exact test on.
+constexpr uint32_t RWR_FLAG_DEBUG_COUNTS = 1u << 16;
+
 // ---------------------------------------------------------------------------
 // Device-side scene records (data layout in HBM, see DESIGN.md §"Data layout").
 //
@@ -36,6 +41,14 @@ struct alignas(16) FaceUV {
 };
 static_assert(sizeof(FaceUV) == 32, "FaceUV is 32 B");
 
+// The three corners again, packed (48 B): what the conservative tile/block
+// frustum tests read, one record per lane, coalesced.
+struct alignas(16) CullRec {
+    float p0[3], p1[3], p2[3];
+    float pad[3];
+};
+static_assert(sizeof(CullRec) == 48, "CullRec is 48 B");
+
 struct Targets {
     uint8_t *color;     // W*H*4 rgba8unorm            (screen_texture, lib.rs:503-515)
     float *depth;       // W*H r32float                (depth_texture_output, lib.rs:482-495)
@@ -43,6 +56,35 @@ struct Targets {
     int32_t *obj_id;    // W*H, aux
     float *hit_t;       // W*H, aux
 };
+
+// Per-frame constants of the conservative culling code (host-computed in double
+// from the camera uniform, context.cpp).  The un-normalised world direction of the
+// ray through pixel-space point (fx, fy) is affine:  dir = A + fx*Bx + fy*By
+// (compute.wgsl:151-159), so every plane through the origin that contains a
+// pixel column x = const or row y = const has the normal  Ux + x*Vx  resp.
+// Uy + y*Vy, and a point q = t*dir(x, y) has  Vx.q = t*vxa,  Vy.q = t*vya.
+struct CullConsts {
+    float A[4], Bx[4], By[4];
+    float Ux[4], Vx[4];    // [3]: L1 norm of the xyz part
+    float Uy[4], Vy[4];
+    float origin[4];
+    float vxa, vya;        // Vx.A, Vy.A  (non-zero for a pinhole camera)
+    float corner_margin;   // kCullRel * max |dir|_1 over the frame
+    uint32_t enabled;      // 0: degenerate camera, cull nothing
+};
+
+// Per-frame, per-face culling record written by k_frame_setup (64 B, one
+// dwordx4 x4 per lane): the face's conservative pixel-space bounding rectangle
+// and, for each of its edges, the affine function  d(x, y) = ea + x*ex + y*ey
+// of dot(edge plane normal, dir(x, y)), signed so that the face can only be hit
+// where all three are >= -me.
+struct alignas(16) FrameTri {
+    float bx0, by0, bx1, by1;
+    float ea[3]; float me0;
+    float ex[3]; float me1;
+    float ey[3]; float me2;
+};
+static_assert(sizeof(FrameTri) == 64, "FrameTri is 64 B");
 
 struct FrameParams {
     rwr_camera_inv_uniform cam;
@@ -52,7 +94,7 @@ struct FrameParams {
     uint32_t n_tris;
     uint32_t tex_w, tex_h;
     uint32_t flags;
-    uint32_t pad;
+    uint32_t wave_cull_min;   // run the per-wave (8x8 tile) cull only for block lists longer than this
     rwr_sphere_buffer_data spheres[RWR_MAX_SPHERES];
     float ambient[4];
     float specular[4];
@@ -64,8 +106,9 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 // kernels_primary.hip
 hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, const rwr_model_face_small *faces,
                           uint32_t n_faces, const rwr_instance_raw *instances, uint32_t n_instances,
-                          TriRecord *tris, FaceUV *face_uv);
+                          TriRecord *tris, FaceUV *face_uv, CullRec *cull);
+hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const CullRec *cull, uint32_t n_tris, FrameTri *ftris);
 hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
-                          const uint32_t *tex, const float *srgb_lut, const Targets &tg);
+                          const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg);
 
 }  // namespace rwr

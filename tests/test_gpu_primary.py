@@ -95,7 +95,13 @@ def test_spheres_only_and_empty_scene(rwr, orc, gpu_ctx, suzanne):
     got = _render_gpu(rwr, gpu_ctx, empty, rwr.make_spheres(), cam_inv, w, h)
     want = orc.render_frame(cam_inv.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), orc.make_spheres(), empty)
     _assert_parity(got, want)
+    assert (got["obj_id"] == -3).any()  # the front sphere (lib.rs:534) covers the rear one from here
+    far = rwr.camera_build_inv_uniform(rwr.make_camera(eye=(3, 0.45, -3.5), target=(0.5, 0.45, -3.5), aspect=w / h))
+    got = _render_gpu(rwr, gpu_ctx, empty, rwr.make_spheres(), far, w, h)
+    want = orc.render_frame(far.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), orc.make_spheres(), empty)
+    _assert_parity(got, want)
     assert (got["obj_id"] == -2).any() and (got["obj_id"] == -3).any()
+    cam_inv = far
     # nothing at all: every pixel keeps the clear value
     got = _render_gpu(rwr, gpu_ctx, empty, rwr.make_spheres([]), cam_inv, w, h)
     assert not got["color"].any() and not got["depth"].any() and (got["obj_id"] == -1).all()
