@@ -150,6 +150,11 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV 
 
     // -- analytic sphere passes, in order (lib.rs:1106-1173) -----------------
     for (uint32_t s = 0; s < p.n_spheres; s++) {
+        // wave-uniform: the tile lies outside the sphere's conservative silhouette bounds
+        const float tx0 = (float)tile_x0, ty0 = (float)tile_y0;
+        if (CULL && ((tx0 + 8.0f < p.sphere_rect[s][0]) || (tx0 > p.sphere_rect[s][2]) ||
+                     (ty0 + 8.0f < p.sphere_rect[s][1]) || (ty0 > p.sphere_rect[s][3])))
+            continue;
         float t;
         f3 n;
         if (sphere_ray_intersect(ld3(p.spheres[s].center), p.spheres[s].radius, O, D, t, n)) {

@@ -186,8 +186,8 @@ RWR_DEV f3 shade_mesh(const FaceUV &fuv, float eu, float ev, float denom, f3 N_f
 // rgba8unorm store conversion: clamp, scale, round half up.
 RWR_DEV uint32_t unorm8(float c)
 {
-    float cc = fminf(fmaxf(c, 0.0f), 1.0f);
-    return (uint32_t)floorf(cc * 255.0f + 0.5f);
+    const float cc = __builtin_amdgcn_fmed3f(c, 0.0f, 1.0f);  // clamp; a NaN gives 0 like fmin(fmax(c,0),1)
+    return (uint32_t)(cc * 255.0f + 0.5f);                   // >= 0, so truncation is floor
 }
 RWR_DEV uint32_t pack_rgba8(float r, float g, float b, float a)
 {

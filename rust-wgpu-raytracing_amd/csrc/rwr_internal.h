@@ -96,6 +96,9 @@ struct FrameParams {
     uint32_t flags;
     uint32_t wave_cull_min;   // run the per-wave (8x8 tile) cull only for block lists longer than this
     rwr_sphere_buffer_data spheres[RWR_MAX_SPHERES];
+    // conservative pixel-space bounds {x0, y0, x1, y1} of each sphere's silhouette
+    // (host-computed per frame, context.cpp); a tile outside them skips the sphere
+    float sphere_rect[RWR_MAX_SPHERES][4];
     float ambient[4];
     float specular[4];
 };
