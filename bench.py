@@ -51,11 +51,6 @@ CONFIGS = {
 }
 
 
-def band_rows(rank: int, world: int, height: int) -> tuple[int, int]:
-    """Contiguous row band of `rank`; bands tile [0,height) exactly."""
-    return (rank * height) // world, ((rank + 1) * height) // world
-
-
 class _DevArray:
     """Zero-copy view of device memory for torch.as_tensor (__cuda_array_interface__)."""
 
@@ -74,6 +69,8 @@ def cpu_baseline(cfg, budget_s: float) -> dict:
     w, h = cfg["width"], cfg["height"]
     cam_inv = orc.camera_build_inv_uniform(orc.make_camera(aspect=w / h, **cfg["camera"]))
     screen, spheres = orc.make_screen(w, h), orc.make_spheres()
+    cores = orc.usable_cores()          # affinity / cgroup share of the box, not the machine's thread count
+    orc.set_num_threads(cores)
     orc.render_frame(cam_inv, screen, spheres, model, want_aux=False)  # warm-up (page in, thread pool)
     times = []
     t_start = time.perf_counter()
@@ -86,7 +83,7 @@ def cpu_baseline(cfg, budget_s: float) -> dict:
     times.sort()
     med = times[len(times) // 2]
     return {
-        "value": round(w * h / med / 1e6, 3), "unit": "Mray/s", "cores": orc.num_threads(), "kind": "port",
+        "value": round(w * h / med / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port", "host_threads_visible": os.cpu_count(),
         "ms_per_frame": round(med * 1e3, 2),
         "sample": f"{len(times)} full {w}x{h} frames of the same workload (median), brute-force per-pixel loop as in the WGSL, "
                   f"gcc -O2 + OpenMP rows; reference wgpu/llvmpipe path not buildable here (no Rust toolchain, no Vulkan ICD)",
@@ -126,6 +123,8 @@ def main() -> int:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    from rwr_amd.partition import band_rows, gather_bands_equal, gather_bands_ragged, make_gather_list
+
     w, h = cfg["width"], cfg["height"]
     r0, r1 = band_rows(rank, world, h)
     model = rwr.load_model_compute(cfg["scene"])
@@ -151,17 +150,15 @@ def main() -> int:
         band = torch.as_tensor(_DevArray(d_color + r0 * w * 4, (r1 - r0) * w * 4), device=f"cuda:{local_rank}")
         if rank == 0:
             frame = torch.empty(h * w * 4, dtype=torch.uint8, device=f"cuda:{local_rank}")
-            gather_list = []
-            for rr in range(world):
-                a, b = band_rows(rr, world, h)
-                gather_list.append(frame[a * w * 4:b * w * 4])
+            gather_list = make_gather_list(frame, world, w, h, 4)
+    gather = gather_bands_equal if h % world == 0 else gather_bands_ragged
 
     render = ctx.render_call(cam_inv, params, (r0, r1))
 
     def step():
         render()
         if world > 1:
-            dist.gather(band, gather_list, dst=0)
+            gather(dist, band, gather_list, rank, 0)   # the frame's single collective (RCCL over xGMI)
 
     def barrier():
         if world > 1:

@@ -236,6 +236,14 @@ RWR_API int rwr_decode_image_rgba8(const uint8_t *bytes, size_t n_bytes,
                                    uint8_t **out_rgba, uint32_t *out_w, uint32_t *out_h);
 RWR_API void rwr_free(void *p);
 
+/* Presentation step (role of src/screenquad.wgsl + the sRGB swapchain,
+ * src/lib.rs:39-64, 310-315, 1186-1224): writes a framebuffer as an RGBA8 PNG.
+ * flip_vertical != 0 puts framebuffer row 0 at the BOTTOM of the image, as the
+ * reference's blit does; encode_srgb != 0 applies the linear->sRGB transfer the
+ * sRGB surface format applies on store. */
+RWR_API int rwr_write_png_rgba8(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height,
+                                int flip_vertical, int encode_srgb);
+
 /* The grid of Instance{position,rotation}.to_raw() of src/lib.rs:400-421 for a
  * given NUM_INSTANCES_PER_ROW / SPACE_BETWEEN; out must hold per_row*per_row. */
 RWR_API int rwr_make_instance_grid(uint32_t per_row, float space_between, rwr_instance_raw *out);

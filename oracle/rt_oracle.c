@@ -636,6 +636,15 @@ OR_API void or_controller_update(float speed, uint32_t keys, OrCamera *camera)
     camera->eye[0] = eye.x; camera->eye[1] = eye.y; camera->eye[2] = eye.z;
 }
 
+OR_API void or_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 OR_API int or_num_threads(void)
 {
 #ifdef _OPENMP

@@ -99,6 +99,7 @@ def lib() -> C.CDLL:
         "rwr_model_info": [vp, vp, vp, vp, vp, vp, vp], "rwr_scene_upload_model": [vp, vp],
         "rwr_decode_image_rgba8": [vp, C.c_size_t, vp, vp, vp], "rwr_free": [vp],
         "rwr_make_instance_grid": [u32, f32, vp],
+        "rwr_write_png_rgba8": [C.c_char_p, vp, u32, u32, i32, i32],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
@@ -176,6 +177,12 @@ def decode_image_rgba8(data: bytes) -> np.ndarray:
     finally:
         lib().rwr_free(out)
     return arr
+
+
+def write_png(path: str, rgba8: np.ndarray, flip_vertical: bool = True, encode_srgb: bool = False):
+    rgba8 = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    h, w = rgba8.shape[:2]
+    _check(lib().rwr_write_png_rgba8(path.encode(), _p(rgba8), w, h, int(flip_vertical), int(encode_srgb)))
 
 
 def load_model_compute(file_name: str, res_dir: str = RES_DIR) -> dict:

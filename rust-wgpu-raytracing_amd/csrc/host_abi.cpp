@@ -2,6 +2,8 @@
 // OBJ/MTL/texture loader, image decoding, instance grid).  The implementations
 // live in ../host/*.hpp so that C++ callers can use them directly; these entry
 // points serve FFI callers (Rust, ctypes).
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -117,6 +119,36 @@ int rwr_decode_image_rgba8(const uint8_t *bytes, size_t n_bytes, uint8_t **out_r
 }
 
 void rwr_free(void *p) { std::free(p); }
+
+int rwr_write_png_rgba8(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, int flip_vertical,
+                        int encode_srgb)
+{
+    if (!path || !rgba8 || width == 0 || height == 0) return set_error(RWR_ERR_INVALID_ARGUMENT, "bad PNG arguments");
+    uint8_t lut[256];
+    for (int i = 0; i < 256; i++) {
+        const double l = i / 255.0;
+        const double e = l <= 0.0031308 ? 12.92 * l : 1.055 * std::pow(l, 1.0 / 2.4) - 0.055;
+        lut[i] = encode_srgb ? (uint8_t)std::lround(e * 255.0) : (uint8_t)i;
+    }
+    std::vector<uint8_t> img((size_t)width * height * 4);
+    for (uint32_t y = 0; y < height; y++) {
+        const uint8_t *src = rgba8 + (size_t)(flip_vertical ? height - 1 - y : y) * width * 4;
+        uint8_t *dst = img.data() + (size_t)y * width * 4;
+        for (uint32_t x = 0; x < width; x++) {
+            dst[4 * x + 0] = lut[src[4 * x + 0]];
+            dst[4 * x + 1] = lut[src[4 * x + 1]];
+            dst[4 * x + 2] = lut[src[4 * x + 2]];
+            dst[4 * x + 3] = src[4 * x + 3];
+        }
+    }
+    const std::vector<uint8_t> png = codec::encode_png_rgba8(img.data(), width, height);
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return set_error(RWR_ERR_IO, "cannot open %s for writing", path);
+    const size_t put = std::fwrite(png.data(), 1, png.size(), f);
+    std::fclose(f);
+    if (put != png.size()) return set_error(RWR_ERR_IO, "short write on %s", path);
+    return RWR_OK;
+}
 
 int rwr_make_instance_grid(uint32_t per_row, float space_between, rwr_instance_raw *out)
 {
