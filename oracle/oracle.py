@@ -163,6 +163,56 @@ def render_frame(cam_inv, screen, spheres, model, want_aux=True) -> dict:
     return {"color": color, "depth": depth, "color_f32": color_f, "obj_id": obj_id, "hit_t": hit_t}
 
 
+PARAMS_DTYPE = np.dtype([("spp", "<u4"), ("max_bounces", "<u4"), ("seed", "<u4"), ("flags", "<u4")])
+INSTANCE_DTYPE = np.dtype([("model", "<f4", (4, 4))])
+
+
+def make_params(spp=1, max_bounces=0, seed=0, flags=0) -> np.ndarray:
+    p = np.zeros(1, dtype=PARAMS_DTYPE)
+    p["spp"], p["max_bounces"], p["seed"], p["flags"] = spp, max_bounces, seed, flags
+    return p
+
+
+def rng_hash(pixel: int, sample: int, dim: int, seed: int) -> int:
+    f = lib().or_rng_hash
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_uint32] * 4
+    return f(pixel, sample, dim, seed)
+
+
+def bounce_direction(n, pixel: int, sample: int, seed: int) -> np.ndarray:
+    n = np.ascontiguousarray(n, dtype=np.float32)
+    out = np.zeros(3, np.float32)
+    f = lib().or_bounce_direction
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    f(_p(n), pixel, sample, seed, _p(out))
+    return out
+
+
+def render_path(cam_inv, screen, params, spheres, model, instances=None, rows=None) -> dict:
+    """The extended integrator (spp / one bounce / instances) on the CPU, brute force."""
+    w, h = int(screen["width"][0]), int(screen["height"][0])
+    r0, r1 = rows if rows is not None else (0, h)
+    color = np.zeros((h, w, 4), np.uint8)
+    depth = np.zeros((h, w), np.float32)
+    color_f = np.zeros((h, w, 4), np.float32)
+    obj_id = np.full((h, w), -1, np.int32)
+    hit_t = np.zeros((h, w), np.float32)
+    verts, faces = model["vertices"], model["faces"]
+    tex = np.ascontiguousarray(model["texture"])
+    n_inst = 0 if instances is None else len(instances)
+    inst = None if n_inst == 0 else np.ascontiguousarray(instances, dtype=INSTANCE_DTYPE)
+    f = lib().or_render_path
+    f.restype = C.c_int
+    rc = f(_p(cam_inv), _p(screen), _p(params), _p(spheres), C.c_uint32(len(spheres)),
+           _p(verts), C.c_uint32(len(verts)), _p(faces), C.c_uint32(len(faces)),
+           _p(inst), C.c_uint32(n_inst), _p(model["material"]), _p(tex), C.c_uint32(tex.shape[1]), C.c_uint32(tex.shape[0]),
+           C.c_uint32(r0), C.c_uint32(r1), _p(color), _p(depth), _p(color_f), _p(obj_id), _p(hit_t))
+    if rc != 0:
+        raise MemoryError("or_render_path")
+    return {"color": color, "depth": depth, "color_f32": color_f, "obj_id": obj_id, "hit_t": hit_t}
+
+
 def num_threads() -> int:
     return lib().or_num_threads()
 

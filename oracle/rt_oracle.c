@@ -462,6 +462,228 @@ OR_API int or_render_frame(const OrCameraInvUniform *cam, const OrScreen *screen
     return 0;
 }
 
+
+/* ================================================================ EXTENSION ==
+ * Multi-sample / one-bounce / instanced integrator (BASELINE.json configs 3-5).
+ * The reference has none of this: the definition below is this
+ * project's own (DESIGN.md "Extended integrator"); spp = 1, bounces = 0, no
+ * instances reproduces or_render_frame bit for bit.
+ *
+ *  - instances: the mesh is replicated once per rigid InstanceRaw matrix,
+ *    world = model * vec4(p, 1) (WGSL mat*vec order), face index =
+ *    instance * n_faces + face; the reference loop then runs over that flat list.
+ *  - sample s of pixel (x, y): sub-pixel position (jx, jy) = (0.5, 0.5) when
+ *    spp == 1, else two uniform numbers from the counter-based hash below keyed
+ *    by (GLOBAL pixel index, s, dimension, seed) — never by tile, band or rank.
+ *  - primary visibility: the reference's passes in order (spheres, then mesh)
+ *    with its depth test.
+ *  - radiance of the sample: L = E(h0) + albedo(h0) * E(h1), where E is the
+ *    reference's local shading of a surface point (ambient + Lambert + Blinn-
+ *    Phong, compute.wgsl:217-234 / sphere 137-152), h1 the nearest hit of ONE
+ *    cosine-distributed bounce ray (no shadow rays; a miss adds nothing).
+ *  - bounce ray: origin P + 1e-4*n, direction from a rejection-sampled unit disk
+ *    point lifted to the hemisphere (Malley) in the orthonormal basis of Duff et
+ *    al. 2017 — only + - * / sqrt, so CPU and GPU agree bit for bit.
+ *  - bounce visibility: nearest t over spheres (in order) then faces (in order),
+ *    strict '<' (earlier candidate wins ties).
+ *  - pixel = (sum over s of L_s, in order, f32) / spp; alpha likewise from 2.0 per
+ *    primary hit.  depth / obj_id / hit_t planes report sample 0.
+ */
+typedef struct { uint32_t spp, max_bounces, seed, flags; } OrRenderParams;
+typedef struct { float model[4][4]; } OrInstance;
+
+static inline uint32_t rng_mix(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+static inline uint32_t rng_hash(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed)
+{
+    uint32_t h = seed ^ 0x9E3779B9u;
+    h = rng_mix(h ^ pixel);
+    h = rng_mix(h ^ (sample * 0x85EBCA6Bu));
+    h = rng_mix(h ^ (dim * 0xC2B2AE35u));
+    return h;
+}
+/* uniform in [0,1) with 24 bits, exact in f32 */
+static inline float rng_uniform(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed)
+{
+    return (float)(rng_hash(pixel, sample, dim, seed) >> 8) * (1.0f / 16777216.0f);
+}
+OR_API uint32_t or_rng_hash(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed) { return rng_hash(pixel, sample, dim, seed); }
+
+/* Cosine-distributed direction about unit normal n. */
+static inline v3 bounce_direction(v3 n, uint32_t pixel, uint32_t sample, uint32_t seed)
+{
+    float a = 0.0f, b = 0.0f;
+    for (uint32_t k = 0; k < 8; k++) {  /* rejection-sample the unit disk; dims 2,3 / 4,5 / ... */
+        float ua = 2.0f * rng_uniform(pixel, sample, 2u + 2u * k, seed) - 1.0f;
+        float ub = 2.0f * rng_uniform(pixel, sample, 3u + 2u * k, seed) - 1.0f;
+        if (ua * ua + ub * ub <= 1.0f) { a = ua; b = ub; break; }
+    }
+    float dz = sqrtf(fmaxf(0.0f, 1.0f - a * a - b * b));
+    /* orthonormal basis (Duff, Burgess, Christensen, Hery, Kensler, Liani, Villemin 2017) */
+    float sign = copysignf(1.0f, n.z);
+    float aa = -1.0f / (sign + n.z);
+    float bb = n.x * n.y * aa;
+    v3 b1 = V3(1.0f + sign * n.x * n.x * aa, sign * bb, -sign * n.x);
+    v3 b2 = V3(bb, sign + n.y * n.y * aa, -n.y);
+    v3 d = V3(a * b1.x + b * b2.x + dz * n.x, a * b1.y + b * b2.y + dz * n.y, a * b1.z + b * b2.z + dz * n.z);
+    return normalize3(d);
+}
+OR_API void or_bounce_direction(const float n[3], uint32_t pixel, uint32_t sample, uint32_t seed, float out[3])
+{
+    v3 d = bounce_direction(v3_from(n), pixel, sample, seed);
+    out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+
+typedef struct {
+    const OrSphere *spheres; uint32_t n_spheres;
+    Mesh mesh;            /* flattened: faces index into world-space verts */
+} Scene;
+
+/* Nearest hit of a bounce ray over spheres then faces; returns kind: -1 none, else
+ * obj id (>= 0 face, -2-k sphere). */
+static inline int32_t scene_nearest(const Scene *sc, Ray ray, HitRecord *out)
+{
+    int32_t id = -1;
+    HitRecord best = kNoHit;
+    for (uint32_t k = 0; k < sc->n_spheres; k++) {
+        HitRecord h = sphere_ray_intersect(v3_from(sc->spheres[k].center), sc->spheres[k].radius, ray);
+        if ((!best.hit && h.hit) || (h.hit && h.distance < best.distance)) { best = h; id = -2 - (int32_t)k; }
+    }
+    if (sc->mesh.n_faces) {
+        int i_min;
+        HitRecord h = mesh_nearest(&sc->mesh, ray, &i_min);
+        if ((!best.hit && h.hit) || (h.hit && h.distance < best.distance)) { best = h; id = i_min; }
+    }
+    *out = best;
+    return id;
+}
+
+static inline v3 shade_any(const Scene *sc, int32_t id, const HitRecord *h, Ray ray, v3 *albedo)
+{
+    if (id >= 0) return shade_mesh(&sc->mesh, (uint32_t)id, h, ray, albedo);
+    return shade_sphere(h, ray, albedo);
+}
+
+OR_API int or_render_path(const OrCameraInvUniform *cam, const OrScreen *screen, const OrRenderParams *params,
+                          const OrSphere *spheres, uint32_t n_spheres,
+                          const OrVertex *verts, uint32_t n_verts, const OrFace *faces, uint32_t n_faces,
+                          const OrInstance *instances, uint32_t n_instances,
+                          const OrMaterial *material, const uint8_t *tex_rgba8, uint32_t tex_w, uint32_t tex_h,
+                          uint32_t row_begin, uint32_t row_end,
+                          uint8_t *color_u8, float *depth_out, float *color_f32, int32_t *obj_id, float *hit_t)
+{
+    const uint32_t W = screen->width, H = screen->height;
+    if (row_end > H) row_end = H;
+    /* flatten instances */
+    OrVertex *wverts = NULL; OrFace *wfaces = NULL;
+    Scene sc;
+    sc.spheres = spheres; sc.n_spheres = n_spheres;
+    sc.mesh.material = material;
+    sc.mesh.tex.rgba = tex_rgba8; sc.mesh.tex.w = tex_w; sc.mesh.tex.h = tex_h;
+    build_srgb_lut(sc.mesh.tex.lut);
+    if (n_instances && n_faces) {
+        wverts = (OrVertex *)malloc((size_t)n_verts * n_instances * sizeof(OrVertex));
+        wfaces = (OrFace *)malloc((size_t)n_faces * n_instances * sizeof(OrFace));
+        if (!wverts || !wfaces) { free(wverts); free(wfaces); return -1; }
+        for (uint32_t k = 0; k < n_instances; k++) {
+            for (uint32_t i = 0; i < n_verts; i++) {
+                OrVertex v = verts[i];
+                v4 p = {v.position[0], v.position[1], v.position[2], 1.0f};
+                v4 q = mat4_mul_v4(instances[k].model, p);
+                v.position[0] = q.x; v.position[1] = q.y; v.position[2] = q.z;
+                wverts[(size_t)k * n_verts + i] = v;
+            }
+            for (uint32_t i = 0; i < n_faces; i++) {
+                OrFace f = faces[i];
+                f.indices[0] += k * n_verts; f.indices[1] += k * n_verts; f.indices[2] += k * n_verts;
+                wfaces[(size_t)k * n_faces + i] = f;
+            }
+        }
+        sc.mesh.verts = wverts; sc.mesh.n_verts = n_verts * n_instances;
+        sc.mesh.faces = wfaces; sc.mesh.n_faces = n_faces * n_instances;
+    } else {
+        sc.mesh.verts = verts; sc.mesh.n_verts = n_verts; sc.mesh.faces = faces; sc.mesh.n_faces = n_faces;
+    }
+    const uint32_t spp = params->spp ? params->spp : 1u;
+    const int bounce = params->max_bounces >= 1;
+
+#pragma omp parallel for schedule(dynamic, 2)
+    for (int y = (int)row_begin; y < (int)row_end; y++) {
+        for (uint32_t x = 0; x < W; x++) {
+            const uint32_t pixel = (uint32_t)y * W + x;
+            const size_t idx = (size_t)pixel;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float depth0 = 0.0f, t0 = 0.0f;
+            int32_t id0 = -1;
+            for (uint32_t s = 0; s < spp; s++) {
+                float jx = 0.5f, jy = 0.5f;
+                if (spp > 1) {
+                    jx = rng_uniform(pixel, s, 0u, params->seed);
+                    jy = rng_uniform(pixel, s, 1u, params->seed);
+                }
+                Ray ray = pixel_to_ray(cam, screen, x, (uint32_t)y, jx, jy);
+                /* the reference's passes, depth-composited in registers */
+                float depth_tex = 0.0f;
+                int32_t id = -1;
+                HitRecord win = kNoHit;
+                for (uint32_t k = 0; k < n_spheres; k++) {
+                    HitRecord h = sphere_ray_intersect(v3_from(spheres[k].center), spheres[k].radius, ray);
+                    if (!h.hit) continue;
+                    float current_depth = 1.0f - depth_tex;
+                    float depth = to_non_linear_depth(h.distance);
+                    if (depth >= current_depth) continue;
+                    depth_tex = 1.0f - depth; id = -2 - (int32_t)k; win = h;
+                }
+                if (sc.mesh.n_faces) {
+                    int i_min;
+                    HitRecord h = mesh_nearest(&sc.mesh, ray, &i_min);
+                    if (h.hit) {
+                        float current_depth = 1.0f - depth_tex;
+                        float depth = to_non_linear_depth(h.distance);
+                        if (!(depth >= current_depth)) { depth_tex = 1.0f - depth; id = i_min; win = h; }
+                    }
+                }
+                if (s == 0) { depth0 = depth_tex; id0 = id; t0 = win.hit ? win.distance : 0.0f; }
+                if (id == -1) continue;
+                v3 albedo;
+                v3 e0 = shade_any(&sc, id, &win, ray, &albedo);
+                acc[0] += e0.x; acc[1] += e0.y; acc[2] += e0.z; acc[3] += 2.0f;
+                if (bounce) {
+                    v3 P = madd3(win.distance, ray.direction, ray.origin);
+                    Ray br;
+                    br.origin = V3(P.x + win.normal.x * 1e-4f, P.y + win.normal.y * 1e-4f, P.z + win.normal.z * 1e-4f);
+                    br.direction = bounce_direction(win.normal, pixel, s, params->seed);
+                    HitRecord h1;
+                    int32_t id1 = scene_nearest(&sc, br, &h1);
+                    if (id1 != -1) {
+                        v3 e1 = shade_any(&sc, id1, &h1, br, NULL);
+                        acc[0] += albedo.x * e1.x; acc[1] += albedo.y * e1.y; acc[2] += albedo.z * e1.z;
+                    }
+                }
+            }
+            const float fs = (float)spp;
+            v3 rgb = V3(acc[0] / fs, acc[1] / fs, acc[2] / fs);
+            float alpha = acc[3] / fs;
+            if (depth_out) depth_out[idx] = depth0;
+            if (color_u8) {
+                color_u8[4 * idx + 0] = unorm8(rgb.x); color_u8[4 * idx + 1] = unorm8(rgb.y);
+                color_u8[4 * idx + 2] = unorm8(rgb.z); color_u8[4 * idx + 3] = unorm8(alpha);
+            }
+            if (color_f32) {
+                color_f32[4 * idx + 0] = rgb.x; color_f32[4 * idx + 1] = rgb.y;
+                color_f32[4 * idx + 2] = rgb.z; color_f32[4 * idx + 3] = alpha;
+            }
+            if (obj_id) obj_id[idx] = id0;
+            if (hit_t) hit_t[idx] = t0;
+        }
+    }
+    free(wverts); free(wfaces);
+    return 0;
+}
+
 /* Single-ray probes used by the known-answer tests. */
 OR_API void or_pixel_to_ray(const OrCameraInvUniform *cam, const OrScreen *screen, uint32_t x, uint32_t y,
                             float jx, float jy, float out_origin[3], float out_dir[3], float out_view_vec[4])

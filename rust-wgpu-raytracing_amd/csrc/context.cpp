@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "bvh.hpp"
 #include "rwr_internal.h"
 
 namespace rwr {
@@ -76,6 +77,16 @@ struct rwr_context {
     DeviceBuffer<FaceUV> d_face_uv;
     DeviceBuffer<CullRec> d_cull;
     DeviceBuffer<FrameTri> d_ftris;
+    // BVH over the (flattened) world-space faces, for bounce rays
+    DeviceBuffer<BvhNode4> d_bvh_nodes;
+    DeviceBuffer<uint32_t> d_bvh_leaf_faces;
+    uint32_t bvh_n_nodes = 0, bvh_depth = 0;
+    // wavefront integrator state
+    DeviceBuffer<float4> d_accum, d_q0, d_q1;
+    DeviceBuffer<float2> d_q2;
+    DeviceBuffer<uint32_t> d_counters;
+    uint32_t last_spp = 0;
+    bool last_had_bounce = false;
     DeviceBuffer<uint32_t> d_tex;
     DeviceBuffer<float> d_lut;
     uint32_t n_verts = 0, n_faces = 0, n_instances = 0, n_tris = 0;
@@ -235,6 +246,25 @@ int rebuild_tris(rwr_context *ctx)
     RWR_HIP_CHECK(ctx->d_ftris.ensure(total));
     RWR_HIP_CHECK(launch_prebake(ctx->stream, ctx->d_verts.ptr, ctx->d_faces.ptr, ctx->n_faces, ctx->d_instances.ptr,
                                  ctx->n_instances, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_cull.ptr));
+    // BVH for incoherent rays, built on the host from the device's own world-space corners
+    // (so instancing arithmetic happens in exactly one place, k_prebake)
+    std::vector<CullRec> host_cull(total);
+    RWR_HIP_CHECK(hipMemcpyAsync(host_cull.data(), ctx->d_cull.ptr, (size_t)total * sizeof(CullRec), hipMemcpyDeviceToHost, ctx->stream));
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    std::vector<float> corners((size_t)total * 9);
+    for (uint32_t i = 0; i < total; i++) {
+        std::memcpy(&corners[9 * (size_t)i + 0], host_cull[i].p0, 12);
+        std::memcpy(&corners[9 * (size_t)i + 3], host_cull[i].p1, 12);
+        std::memcpy(&corners[9 * (size_t)i + 6], host_cull[i].p2, 12);
+    }
+    const Bvh bvh = build_bvh(corners.data(), total);
+    RWR_HIP_CHECK(ctx->d_bvh_nodes.ensure(bvh.nodes.size()));
+    RWR_HIP_CHECK(ctx->d_bvh_leaf_faces.ensure(bvh.leaf_faces.size() ? bvh.leaf_faces.size() : 1));
+    RWR_HIP_CHECK(hipMemcpy(ctx->d_bvh_nodes.ptr, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode4), hipMemcpyHostToDevice));
+    if (!bvh.leaf_faces.empty())
+        RWR_HIP_CHECK(hipMemcpy(ctx->d_bvh_leaf_faces.ptr, bvh.leaf_faces.data(), bvh.leaf_faces.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->bvh_n_nodes = (uint32_t)bvh.nodes.size();
+    ctx->bvh_depth = bvh.max_depth;
     ctx->n_tris = total;
     ctx->tris_dirty = false;
     return RWR_OK;
@@ -301,7 +331,9 @@ void rwr_ctx_destroy(rwr_context *ctx)
     DeviceGuard g(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
-    ctx->d_tris.release(); ctx->d_face_uv.release(); ctx->d_cull.release(); ctx->d_ftris.release(); ctx->d_tex.release(); ctx->d_lut.release();
+    ctx->d_tris.release(); ctx->d_face_uv.release(); ctx->d_cull.release(); ctx->d_ftris.release();
+    ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
+    ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_counters.release(); ctx->d_tex.release(); ctx->d_lut.release();
     ctx->d_color.release(); ctx->d_depth.release(); ctx->d_color_f32.release();
     ctx->d_obj_id.release(); ctx->d_hit_t.release();
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -440,8 +472,9 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     if (params) rp = *params;
     if (rp.spp == 0) return set_error(RWR_ERR_INVALID_ARGUMENT, "spp must be >= 1");
     if (rp.max_bounces > 1) return set_error(RWR_ERR_UNSUPPORTED, "max_bounces > 1 is not supported");
-    if (rp.spp != 1 || rp.max_bounces != 0 || (rp.flags & RWR_FLAG_USE_BVH))
-        return set_error(RWR_ERR_UNSUPPORTED, "the wavefront integrator is not built into this library yet");
+    if (rp.flags & RWR_FLAG_USE_BVH) return set_error(RWR_ERR_UNSUPPORTED, "RWR_FLAG_USE_BVH for primary rays is not implemented");
+    if (rp.spp > 4096) return set_error(RWR_ERR_INVALID_ARGUMENT, "spp must be <= 4096");
+    const bool wavefront = rp.spp != 1 || rp.max_bounces != 0;
 
     DeviceGuard g(ctx->device);
     const size_t n = (size_t)ctx->screen.width * ctx->screen.height;
@@ -476,6 +509,9 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     CullConsts cc;
     compute_cull_consts(*camera, ctx->screen.width, ctx->screen.height, cc);
     compute_sphere_rects(cc, ctx->spheres, ctx->n_spheres, ctx->screen.width, ctx->screen.height, fp.sphere_rect);
+    fp.spp = rp.spp;
+    fp.seed = rp.seed;
+    fp.bounces = rp.max_bounces;
     if (ctx->n_tris && !(rp.flags & RWR_FLAG_NO_CULL)) {
         // Per-frame, per-face culling records: they depend on the camera, so they are rebuilt
         // every frame, on the render stream just ahead of the render kernel.  (Running this
@@ -484,10 +520,37 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         // cross-stream event waits cost more than the kernel.)
         RWR_HIP_CHECK(launch_frame_setup(ctx->stream, cc, ctx->d_cull.ptr, ctx->n_tris, ctx->d_ftris.ptr));
     }
-    RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, ctx->d_lut.ptr, tg));
+    if (!wavefront) {
+        RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, ctx->d_lut.ptr, tg));
+        ctx->last_spp = 0;
+    } else {
+        // wavefront integrator: per sample pass, primary stage then (queue-driven) bounce stage
+        const size_t band_px = (size_t)ctx->screen.width * (row_end - row_begin);
+        RWR_HIP_CHECK(ctx->d_accum.ensure(n));
+        RWR_HIP_CHECK(ctx->d_counters.ensure(rp.spp));
+        if (rp.max_bounces) {
+            RWR_HIP_CHECK(ctx->d_q0.ensure(band_px));
+            RWR_HIP_CHECK(ctx->d_q1.ensure(band_px));
+            RWR_HIP_CHECK(ctx->d_q2.ensure(band_px));
+        }
+        RWR_HIP_CHECK(hipMemsetAsync(ctx->d_counters.ptr, 0, (size_t)rp.spp * sizeof(uint32_t), ctx->stream));
+        const WfBuffers wf{ctx->d_accum.ptr, ctx->d_q0.ptr, ctx->d_q1.ptr, ctx->d_q2.ptr, ctx->d_counters.ptr};
+        const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
+        for (uint32_t sidx = 0; sidx < rp.spp; sidx++) {
+            fp.sample = sidx;
+            RWR_HIP_CHECK(launch_wf_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr,
+                                            ctx->d_lut.ptr, tg, wf));
+            if (rp.max_bounces)
+                RWR_HIP_CHECK(launch_wf_bounce(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, bvh, ctx->d_tex.ptr,
+                                               ctx->d_lut.ptr, wf, (uint32_t)band_px));
+        }
+        RWR_HIP_CHECK(launch_wf_resolve(ctx->stream, fp, tg, wf));
+        ctx->last_spp = rp.spp;
+        ctx->last_had_bounce = rp.max_bounces != 0;
+    }
     ctx->aux_valid = aux;
-    ctx->last_primary = (uint64_t)ctx->screen.width * (row_end - row_begin);
-    ctx->last_bounce = 0;
+    ctx->last_primary = (uint64_t)ctx->screen.width * (row_end - row_begin) * rp.spp;
+    ctx->last_bounce = 0;  // filled in lazily by rwr_last_render_stats from the pass counters
     return RWR_OK;
 }
 
@@ -552,6 +615,14 @@ int rwr_timer_end(rwr_context *ctx, float *elapsed_ms)
 int rwr_last_render_stats(rwr_context *ctx, uint64_t *primary_rays, uint64_t *bounce_rays)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (ctx->last_spp && ctx->last_had_bounce) {
+        DeviceGuard g(ctx->device);
+        std::vector<uint32_t> counts(ctx->last_spp);
+        RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        RWR_HIP_CHECK(hipMemcpy(counts.data(), ctx->d_counters.ptr, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        ctx->last_bounce = 0;
+        for (uint32_t c : counts) ctx->last_bounce += c;
+    }
     if (primary_rays) *primary_rays = ctx->last_primary;
     if (bounce_rays) *bounce_rays = ctx->last_bounce;
     return RWR_OK;

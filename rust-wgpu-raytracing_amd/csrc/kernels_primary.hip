@@ -23,8 +23,7 @@
 //    Ascending order + strict '<' reproduces the reference's lowest-index tie
 //    rule; skipped faces are ones no ray of the tile can hit, so the result is
 //    bit-identical to the brute-force loop (checked against RWR_FLAG_NO_CULL).
-#include "rwr_cull.h"
-#include "rwr_device.h"
+#include "rwr_primary.h"
 
 namespace rwr {
 
@@ -128,8 +127,7 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV 
           const Targets tg)
 {
     __shared__ float s_lut[256];
-    __shared__ uint32_t s_cand[256];   // block-level candidate faces of the current batch, ascending
-    __shared__ uint32_t s_wave_cnt[4];
+    __shared__ PrimaryShared s_prim;
     s_lut[threadIdx.x] = srgb_lut[threadIdx.x];
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -142,112 +140,28 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV 
     const f3 O = ld3(p.cam.origin);
     const f3 D = pixel_to_ray_dir(p.cam, px, py, 0.5f, 0.5f, p.width, p.height);
 
-    // Framebuffer state of this pixel, as the reference's cleared textures hold it.
-    float depth_tex = 0.0f;                            // depth_texture_* after the clear (lib.rs:1024-1104)
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;  // screen_texture after the clear
-    int32_t obj = -1;
-    float hit_t = 0.0f;
+    PrimaryHit r;
+    uint32_t dbg_listed = 0, dbg_tested = 0;  // RWR_FLAG_DEBUG_COUNTS (aux builds only)
+    primary_visibility<CULL, AUX>(p, tris, ftris, s_prim, blk_x0, tile_x0, tile_y0, O, D, r, dbg_listed, dbg_tested);
+    if (!p.n_tris) __syncthreads();  // s_lut (the mesh loop's barriers cover it otherwise)
 
-    // -- analytic sphere passes, in order (lib.rs:1106-1173) -----------------
-    for (uint32_t s = 0; s < p.n_spheres; s++) {
-        // wave-uniform: the tile lies outside the sphere's conservative silhouette bounds
-        const float tx0 = (float)tile_x0, ty0 = (float)tile_y0;
-        if (CULL && ((tx0 + 8.0f < p.sphere_rect[s][0]) || (tx0 > p.sphere_rect[s][2]) ||
-                     (ty0 + 8.0f < p.sphere_rect[s][1]) || (ty0 > p.sphere_rect[s][3])))
-            continue;
-        float t;
-        f3 n;
-        if (sphere_ray_intersect(ld3(p.spheres[s].center), p.spheres[s].radius, O, D, t, n)) {
-            const float current_depth = 1.0f - depth_tex;  // sphere/compute.wgsl:130
-            const float depth = to_non_linear_depth(t);
-            if (!(depth >= current_depth)) {
-                const f3 c = shade_sphere(n, D);
-                cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
-                depth_tex = 1.0f - depth;
-                obj = -2 - (int32_t)s;
-                hit_t = t;
-            }
-        }
-    }
-
-    // -- mesh pass (lib.rs:1174-1184) -----------------------------------------
-    MeshHit best;
-    best.have = false; best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.ndotd = 0.0f; best.idx = 0u;
-    uint32_t dbg_tested = 0, dbg_listed = 0;  // RWR_FLAG_DEBUG_COUNTS (aux builds only)
-
-    if (p.n_tris) {
-        const bool cull_on = CULL;
-        const float by0 = (float)tile_y0, bx0 = (float)blk_x0, tx0 = (float)tile_x0;
-        const TileRect blk_rect = {bx0, by0, bx0 + 32.0f, by0 + 8.0f};
-        const TileRect tile_rect = {tx0, by0, tx0 + 8.0f, by0 + 8.0f};
-        for (uint32_t base = 0; base < p.n_tris; base += 256u) {
-            // level 1: 256 faces vs the block frustum, order-preserving compaction into LDS
-            const uint32_t j = base + threadIdx.x;
-            bool keep = j < p.n_tris;
-            if (cull_on && keep) keep = !rect_culls(ftris[j], blk_rect);
-            const unsigned long long m = __ballot(keep);
-            if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(m);
-            __syncthreads();
-            uint32_t off = 0, total = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < 4; w++) {
-                const uint32_t c = s_wave_cnt[w];
-                off += (w < wave) ? c : 0u;
-                total += c;
-            }
-            total = __builtin_amdgcn_readfirstlane(total);
-            if (AUX) dbg_listed += total;
-            if (keep) s_cand[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
-            __syncthreads();
-            // level 2: list entries vs this wave's tile frustum (skipped for short lists,
-            // where it costs more than the exact tests it saves), then the exact test
-            const bool wave_cull = cull_on && total > p.wave_cull_min;
-            for (uint32_t cbase = 0; cbase < total; cbase += 64u) {
-                const uint32_t e = cbase + lane;
-                bool keep2 = e < total;
-                const uint32_t my_idx = keep2 ? s_cand[e] : 0u;
-                if (wave_cull && keep2) keep2 = !rect_culls(ftris[my_idx], tile_rect);
-                unsigned long long m2 = __ballot(keep2);
-                while (m2) {
-                    const uint32_t b = (uint32_t)__builtin_ctzll(m2);
-                    m2 &= m2 - 1ull;
-                    // wave-uniform face index: the record comes in through scalar loads
-                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_idx, (int)b);
-                    intersect_and_select(tris[idx], idx, O, D, best);
-                    if (AUX) dbg_tested++;
-                }
-            }
-            if (base + 256u < p.n_tris) __syncthreads();  // s_cand / s_wave_cnt are rewritten by the next batch
-        }
-    } else {
-        __syncthreads();  // s_lut
-    }
-
-    if (best.have) {
-        const float current_depth = 1.0f - depth_tex;  // compute.wgsl:210
-        const float depth = to_non_linear_depth(best.t);
-        if (!(depth >= current_depth)) {
-            const TriRecord &T = tris[best.idx];
-            f3 N = ld3(T.N);
-            if (best.ndotd > 0.0f) N = neg3(N);          // compute.wgsl:140-142
-            const f3 c = shade_mesh(face_uv[best.idx], best.u, best.v, T.denom, N, D, p.ambient, p.specular, tex,
-                                    p.tex_w, p.tex_h, s_lut, nullptr);
-            cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
-            depth_tex = 1.0f - depth;
-            obj = (int32_t)best.idx;
-            hit_t = best.t;
-        }
+    // A pixel no pass wrote keeps the clear value (0,0,0,0); a written one gets
+    // final_color with alpha 1 + 1 (compute.wgsl:231-234).
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
+    if (r.obj != -1) {
+        const f3 c = shade_winner(p, r, tris, face_uv, tex, s_lut, O, D, nullptr);
+        cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
     }
 
     if (in_range) {
         const size_t o = (size_t)py * p.width + px;
         reinterpret_cast<uint32_t *>(tg.color)[o] = pack_rgba8(cr, cg, cb, ca);
-        tg.depth[o] = depth_tex;
+        tg.depth[o] = r.depth_tex;
         if (AUX) {
             reinterpret_cast<float4 *>(tg.color_f32)[o] = make_float4(cr, cg, cb, ca);
             const bool dbg = (p.flags & RWR_FLAG_DEBUG_COUNTS) != 0;
-            tg.obj_id[o] = dbg ? (int32_t)dbg_listed : obj;
-            tg.hit_t[o] = dbg ? (float)dbg_tested : hit_t;
+            tg.obj_id[o] = dbg ? (int32_t)dbg_listed : r.obj;
+            tg.hit_t[o] = dbg ? (float)dbg_tested : r.t;
         }
     }
 }

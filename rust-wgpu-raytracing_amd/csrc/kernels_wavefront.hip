@@ -1,0 +1,219 @@
+// Wavefront integrator (extension; BASELINE.json configs 3-5 — the reference traces
+// one centre ray per pixel and has no bounce).  Per sample pass:
+//
+//   k_wf_primary  one lane per pixel: jittered primary ray through the same fused
+//                 visibility code as the frame kernel (rwr_primary.h), local shading
+//                 E(h0) added to the RGBA32F accumulator; pixels that hit a surface
+//                 build their cosine-distributed bounce ray and APPEND it to the ray
+//                 queue in HBM: __ballot + popcount prefix inside the wave, ONE
+//                 atomicAdd per wave on the pass counter (wavefront compaction — rays
+//                 that left the scene cost nothing downstream).
+//   k_wf_bounce   one lane per queued ray (coalesced 16-byte SoA loads): analytic
+//                 spheres + per-lane BVH traversal with LDS-staged nodelets
+//                 (rwr_bvh.h), shading of the second hit, accumulator += albedo * E(h1).
+//   k_wf_resolve  accumulator / spp -> RGBA8 (+ float plane).
+//
+// Pixels and the RNG are keyed by GLOBAL pixel index, so any row-band split over GPUs
+// produces the same bits.
+#include "rwr_bvh.h"
+#include "rwr_primary.h"
+
+namespace rwr {
+
+template <bool AUX, bool CULL>
+__global__ void __launch_bounds__(256, 8)
+k_wf_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
+             const FrameTri *__restrict__ ftris, const uint32_t *__restrict__ tex, const float *__restrict__ srgb_lut,
+             const Targets tg, const WfBuffers wf)
+{
+    __shared__ float s_lut[256];
+    __shared__ PrimaryShared s_prim;
+    s_lut[threadIdx.x] = srgb_lut[threadIdx.x];
+
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t blk_x0 = blockIdx.x * 32u;
+    const uint32_t tile_x0 = blk_x0 + wave * 8u;
+    const uint32_t tile_y0 = p.row_begin + blockIdx.y * 8u;
+    const uint32_t px = tile_x0 + (lane & 7u), py = tile_y0 + (lane >> 3);
+    const bool in_range = (px < p.width) && (py < p.row_end);
+    const uint32_t pixel = py * p.width + px;  // GLOBAL pixel index: RNG key and accumulator slot
+
+    float jx = 0.5f, jy = 0.5f;
+    if (p.spp > 1u) {
+        jx = rng_uniform(pixel, p.sample, 0u, p.seed);
+        jy = rng_uniform(pixel, p.sample, 1u, p.seed);
+    }
+    const f3 O = ld3(p.cam.origin);
+    const f3 D = pixel_to_ray_dir(p.cam, px, py, jx, jy, p.width, p.height);
+
+    PrimaryHit r;
+    uint32_t dl = 0, dt = 0;
+    primary_visibility<CULL, false>(p, tris, ftris, s_prim, blk_x0, tile_x0, tile_y0, O, D, r, dl, dt);
+    if (!p.n_tris) __syncthreads();  // s_lut
+
+    const bool hit = r.obj != -1;
+    float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    f3 albedo = mk3(0.0f, 0.0f, 0.0f);
+    if (hit) {
+        const f3 c = shade_winner(p, r, tris, face_uv, tex, s_lut, O, D, &albedo);
+        e0 = make_float4(c.x, c.y, c.z, 2.0f);
+    }
+    if (in_range) {
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (p.sample != 0u) acc = wf.accum[pixel];
+        acc.x += e0.x; acc.y += e0.y; acc.z += e0.z; acc.w += e0.w;
+        wf.accum[pixel] = acc;
+        if (p.sample == 0u) {  // depth / aux planes report sample 0
+            tg.depth[pixel] = r.depth_tex;
+            if (AUX) {
+                tg.obj_id[pixel] = r.obj;
+                tg.hit_t[pixel] = r.t;
+            }
+        }
+    }
+
+    // -- bounce ray generation + wavefront compaction ---------------------------
+    const bool emit = hit && in_range && p.bounces != 0u;
+    f3 O1 = mk3(0, 0, 0), D1 = mk3(0, 0, 1);
+    if (emit) {
+        // the surface normal as the reference's HitRecord holds it (exact: it steers the bounce)
+        f3 n;
+        const f3 P = along(O, r.t, D);
+        if (r.obj >= 0) {
+            f3 N = ld3(tris[r.obj].N);
+            if (r.mesh.ndotd > 0.0f) N = neg3(N);
+            n = normalize3(N);
+        } else {
+            n = normalize3(sub3(P, ld3(p.spheres[-2 - r.obj].center)));
+        }
+        O1 = mk3(P.x + n.x * 1e-4f, P.y + n.y * 1e-4f, P.z + n.z * 1e-4f);
+        D1 = bounce_direction(n, pixel, p.sample, p.seed);
+    }
+    const unsigned long long m = __ballot(emit);
+    if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&wf.counters[p.sample], (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (emit) {
+            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            wf.q0[slot] = make_float4(O1.x, O1.y, O1.z, __uint_as_float(pixel));
+            wf.q1[slot] = make_float4(D1.x, D1.y, D1.z, albedo.x);
+            wf.q2[slot] = make_float2(albedo.y, albedo.z);
+        }
+    }
+}
+
+template <bool NODES_IN_LDS>
+__global__ void __launch_bounds__(256)
+k_wf_bounce(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
+            const BvhDevice bvh, const uint32_t *__restrict__ tex, const float *__restrict__ srgb_lut, const WfBuffers wf)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const uint32_t count = wf.counters[p.sample];
+    if (blockIdx.x * 256u >= count) return;  // whole workgroup beyond the queue (uniform)
+
+    // LDS carve: [nodelets][stack][lut]
+    BvhNode4 *s_nodes = reinterpret_cast<BvhNode4 *>(s_dyn);
+    const uint32_t node_bytes = NODES_IN_LDS ? bvh.n_nodes * (uint32_t)sizeof(BvhNode4) : 0u;
+    uint32_t *s_stack = reinterpret_cast<uint32_t *>(s_dyn + node_bytes);
+    float *s_lut = reinterpret_cast<float *>(s_dyn + node_bytes + bvh.stack_depth * 256u * 4u);
+    if (NODES_IN_LDS) {
+        const float4 *src = reinterpret_cast<const float4 *>(bvh.nodes);
+        float4 *dst = reinterpret_cast<float4 *>(s_nodes);
+        for (uint32_t i = threadIdx.x; i < bvh.n_nodes * 8u; i += 256u) dst[i] = src[i];
+    }
+    s_lut[threadIdx.x] = srgb_lut[threadIdx.x];
+    __syncthreads();
+
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;  // no barrier below
+    const float4 a = wf.q0[i], b = wf.q1[i];
+    const float2 c = wf.q2[i];
+    const f3 O = mk3(a.x, a.y, a.z), D = mk3(b.x, b.y, b.z);
+    const uint32_t pixel = __float_as_uint(a.w);
+    const f3 thr = mk3(b.w, c.x, c.y);
+
+    // nearest over spheres (in order), then the mesh; strict '<' keeps the earlier candidate on ties
+    bool have = false;
+    float best_t = 0.0f;
+    int32_t obj = -1;
+    for (uint32_t s = 0; s < p.n_spheres; s++) {
+        float t;
+        if (sphere_ray_intersect_t(ld3(p.spheres[s].center), p.spheres[s].radius, O, D, t)) {
+            if (!have || t < best_t) { have = true; best_t = t; obj = -2 - (int32_t)s; }
+        }
+    }
+    MeshHit mh;
+    mh.have = false; mh.t = 0.0f; mh.u = 0.0f; mh.v = 0.0f; mh.ndotd = 0.0f; mh.idx = 0u;
+    if (p.n_tris) {
+        if (NODES_IN_LDS) bvh_nearest(s_nodes, bvh.leaf_faces, tris, s_stack, O, D, mh);
+        else bvh_nearest(bvh.nodes, bvh.leaf_faces, tris, s_stack, O, D, mh);
+        if (mh.have && (!have || mh.t < best_t)) { have = true; best_t = mh.t; obj = (int32_t)mh.idx; }
+    }
+    if (!have) return;
+
+    PrimaryHit r;
+    r.depth_tex = 0.0f; r.obj = obj; r.t = best_t; r.mesh = mh;
+    const f3 e1 = shade_winner(p, r, tris, face_uv, tex, s_lut, O, D, nullptr);
+    float4 acc = wf.accum[pixel];
+    acc.x += thr.x * e1.x; acc.y += thr.y * e1.y; acc.z += thr.z * e1.z;
+    wf.accum[pixel] = acc;
+}
+
+template <bool AUX>
+__global__ void __launch_bounds__(256)
+k_wf_resolve(const FrameParams p, const Targets tg, const WfBuffers wf)
+{
+    const uint32_t n = p.width * (p.row_end - p.row_begin);
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pixel = p.row_begin * p.width + i;
+    const float4 acc = wf.accum[pixel];
+    const float fs = (float)p.spp;
+    const float r = acc.x / fs, g = acc.y / fs, b = acc.z / fs, a = acc.w / fs;
+    reinterpret_cast<uint32_t *>(tg.color)[pixel] = pack_rgba8(r, g, b, a);
+    if (AUX) reinterpret_cast<float4 *>(tg.color_f32)[pixel] = make_float4(r, g, b, a);
+}
+
+hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+                             const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg,
+                             const WfBuffers &wf)
+{
+    if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
+    const dim3 grid((fp.width + 31u) / 32u, (fp.row_end - fp.row_begin + 7u) / 8u);
+    const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0, do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
+    if (aux && do_cull) hipLaunchKernelGGL((k_wf_primary<true, true>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg, wf);
+    else if (aux) hipLaunchKernelGGL((k_wf_primary<true, false>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg, wf);
+    else if (do_cull) hipLaunchKernelGGL((k_wf_primary<false, true>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg, wf);
+    else hipLaunchKernelGGL((k_wf_primary<false, false>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg, wf);
+    return hipGetLastError();
+}
+
+hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+                            const BvhDevice &bvh, const uint32_t *tex, const float *srgb_lut, const WfBuffers &wf,
+                            uint32_t max_rays)
+{
+    if (max_rays == 0) return hipSuccess;
+    const dim3 grid((max_rays + 255u) / 256u);
+    const size_t fixed = (size_t)bvh.stack_depth * 256u * 4u + 256u * 4u;
+    const size_t node_bytes = (size_t)bvh.n_nodes * sizeof(BvhNode4);
+    // nodelets go to LDS when they leave room for >= 2 workgroups per CU (160 KiB LDS)
+    if (node_bytes + fixed <= 64u * 1024u) {
+        hipLaunchKernelGGL((k_wf_bounce<true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, face_uv, bvh, tex, srgb_lut, wf);
+    } else {
+        hipLaunchKernelGGL((k_wf_bounce<false>), grid, dim3(256), fixed, s, fp, tris, face_uv, bvh, tex, srgb_lut, wf);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf)
+{
+    if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
+    const uint32_t n = fp.width * (fp.row_end - fp.row_begin);
+    const dim3 grid((n + 255u) / 256u);
+    if (fp.flags & RWR_FLAG_AUX_OUTPUTS) hipLaunchKernelGGL((k_wf_resolve<true>), grid, dim3(256), 0, s, fp, tg, wf);
+    else hipLaunchKernelGGL((k_wf_resolve<false>), grid, dim3(256), 0, s, fp, tg, wf);
+    return hipGetLastError();
+}
+
+}  // namespace rwr

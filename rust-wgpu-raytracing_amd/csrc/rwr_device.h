@@ -91,8 +91,9 @@ RWR_DEV f3 cnormalize(f3 a)
     return mk3(a.x * r, a.y * r, a.z * r);
 }
 
-// sphereRayIntersect, sphere/compute.wgsl:63-85 (the normal feeds only the colour).  Returns hit; t and normal on hit.
-RWR_DEV bool sphere_ray_intersect(f3 center, float radius, f3 O, f3 D, float &t_out, f3 &n_out)
+// sphereRayIntersect, sphere/compute.wgsl:63-85: hit and distance (the normal, which
+// feeds only colour / the bounce, is derived from t by the caller).
+RWR_DEV bool sphere_ray_intersect_t(f3 center, float radius, f3 O, f3 D, float &t_out)
 {
     f3 oc = sub3(O, center);
     float a = dot3(D, D);
@@ -103,13 +104,9 @@ RWR_DEV bool sphere_ray_intersect(f3 center, float radius, f3 O, f3 D, float &t_
     float sq = sqrtf(discriminant);
     float t1 = (-b - sq) / (2.0f * a);
     float t2 = (-b + sq) / (2.0f * a);
-    float t;
-    if (t1 >= 0.0f) t = t1;
-    else if (t2 >= 0.0f) t = t2;
+    if (t1 >= 0.0f) t_out = t1;
+    else if (t2 >= 0.0f) t_out = t2;
     else return false;
-    f3 P = along(O, t, D);
-    n_out = cnormalize(sub3(P, center));
-    t_out = t;
     return true;
 }
 
@@ -236,6 +233,47 @@ RWR_DEV void intersect_and_select(const TriRecord &T, uint32_t idx, f3 O, f3 D, 
         best.ndotd = ndotd;
         best.idx = idx;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Extension (no reference counterpart; DESIGN.md "Extended integrator"): the
+// counter-based RNG and the cosine-distributed bounce direction.  Integer hash +
+// only + - * / sqrt on floats, written operation for operation like the oracle, so
+// CPU and GPU agree bit for bit and the result never depends on tile, band or rank.
+RWR_DEV uint32_t rng_mix(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+RWR_DEV uint32_t rng_hash(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed)
+{
+    uint32_t h = seed ^ 0x9E3779B9u;
+    h = rng_mix(h ^ pixel);
+    h = rng_mix(h ^ (sample * 0x85EBCA6Bu));
+    h = rng_mix(h ^ (dim * 0xC2B2AE35u));
+    return h;
+}
+RWR_DEV float rng_uniform(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed)
+{
+    return (float)(rng_hash(pixel, sample, dim, seed) >> 8) * (1.0f / 16777216.0f);
+}
+
+RWR_DEV f3 bounce_direction(f3 n, uint32_t pixel, uint32_t sample, uint32_t seed)
+{
+    float a = 0.0f, b = 0.0f;
+    for (uint32_t k = 0; k < 8u; k++) {  // rejection-sample the unit disk
+        const float ua = 2.0f * rng_uniform(pixel, sample, 2u + 2u * k, seed) - 1.0f;
+        const float ub = 2.0f * rng_uniform(pixel, sample, 3u + 2u * k, seed) - 1.0f;
+        if (ua * ua + ub * ub <= 1.0f) { a = ua; b = ub; break; }
+    }
+    const float dz = sqrtf(fmaxf(0.0f, 1.0f - a * a - b * b));
+    const float sign = copysignf(1.0f, n.z);
+    const float aa = -1.0f / (sign + n.z);
+    const float bb = n.x * n.y * aa;
+    const f3 b1 = mk3(1.0f + sign * n.x * n.x * aa, sign * bb, -sign * n.x);
+    const f3 b2 = mk3(bb, sign + n.y * n.y * aa, -n.y);
+    const f3 d = mk3(a * b1.x + b * b2.x + dz * n.x, a * b1.y + b * b2.y + dz * n.y, a * b1.z + b * b2.z + dz * n.z);
+    return normalize3(d);
 }
 
 }  // namespace rwr

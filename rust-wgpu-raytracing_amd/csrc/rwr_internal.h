@@ -95,6 +95,8 @@ struct FrameParams {
     uint32_t tex_w, tex_h;
     uint32_t flags;
     uint32_t wave_cull_min;   // run the per-wave (8x8 tile) cull only for block lists longer than this
+    // wavefront integrator (extension): sample being traced, samples per pixel, RNG seed, bounces
+    uint32_t sample, spp, seed, bounces;
     rwr_sphere_buffer_data spheres[RWR_MAX_SPHERES];
     // conservative pixel-space bounds {x0, y0, x1, y1} of each sphere's silhouette
     // (host-computed per frame, context.cpp); a tile outside them skips the sphere
@@ -110,6 +112,30 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, const rwr_model_face_small *faces,
                           uint32_t n_faces, const rwr_instance_raw *instances, uint32_t n_instances,
                           TriRecord *tris, FaceUV *face_uv, CullRec *cull);
+// Wavefront integrator state (kernels_wavefront.hip).  Ray queue = SoA in HBM, 40 B per
+// bounce ray: q0 = {O.xyz, pixel}, q1 = {D.xyz, thr.r}, q2 = {thr.g, thr.b}.
+struct WfBuffers {
+    float4 *accum;        // W*H RGBA32F running sums (rgb = radiance, a = 2 * primary hits)
+    float4 *q0, *q1;
+    float2 *q2;
+    uint32_t *counters;   // one per sample pass: bounce rays emitted
+};
+struct BvhNode4;
+struct BvhDevice {
+    const BvhNode4 *nodes;
+    const uint32_t *leaf_faces;
+    uint32_t n_nodes;
+    uint32_t stack_depth;  // 3 * tree depth + 2
+};
+
+hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+                             const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg,
+                             const WfBuffers &wf);
+hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+                            const BvhDevice &bvh, const uint32_t *tex, const float *srgb_lut, const WfBuffers &wf,
+                            uint32_t max_rays);
+hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf);
+
 hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const CullRec *cull, uint32_t n_tris, FrameTri *ftris);
 hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
                           const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg);

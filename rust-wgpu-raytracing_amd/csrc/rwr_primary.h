@@ -1,0 +1,138 @@
+// Primary-ray visibility for one 32x8-pixel workgroup (4 waves of 8x8 pixels, one
+// lane per pixel): the reference's sphere passes and mesh pass with its depth
+// test (/root/reference/src/lib.rs:1106-1184), composited in registers.
+// Shared by the fused frame kernel (kernels_primary.hip) and the first stage of
+// the wavefront integrator (kernels_wavefront.hip).
+#pragma once
+
+#include "rwr_cull.h"
+#include "rwr_device.h"
+
+namespace rwr {
+
+// LDS a workgroup needs for primary_visibility.
+struct PrimaryShared {
+    uint32_t cand[256];   // block-level candidate faces of the current batch, ascending
+    uint32_t wave_cnt[4];
+};
+
+// What the pixel shows after all passes.
+struct PrimaryHit {
+    float depth_tex;  // value of depth_texture_output (0 = cleared)
+    int32_t obj;      // >= 0 face, -1 nothing, -2-k sphere k
+    float t;          // distance of the winning hit (0 if none)
+    MeshHit mesh;     // valid when obj >= 0
+};
+
+// Must be called by all 256 threads of the workgroup (contains barriers).
+// O, D: this lane's ray.  (tile_x0, tile_y0): the wave's 8x8 tile; blk_x0: the workgroup's 32-wide block.
+template <bool CULL, bool COUNT>
+RWR_DEV void primary_visibility(const FrameParams &p, const TriRecord *__restrict__ tris,
+                                const FrameTri *__restrict__ ftris, PrimaryShared &sh, uint32_t blk_x0,
+                                uint32_t tile_x0, uint32_t tile_y0, f3 O, f3 D, PrimaryHit &r, uint32_t &dbg_listed,
+                                uint32_t &dbg_tested)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    r.depth_tex = 0.0f;  // depth_texture_* after the clear (lib.rs:1024-1104)
+    r.obj = -1;
+    r.t = 0.0f;
+
+    // -- analytic sphere passes, in order (lib.rs:1106-1173) -----------------
+    const float tx0 = (float)tile_x0, ty0 = (float)tile_y0;
+    for (uint32_t s = 0; s < p.n_spheres; s++) {
+        // wave-uniform: the tile lies outside the sphere's conservative silhouette bounds
+        if (CULL && ((tx0 + 8.0f < p.sphere_rect[s][0]) || (tx0 > p.sphere_rect[s][2]) ||
+                     (ty0 + 8.0f < p.sphere_rect[s][1]) || (ty0 > p.sphere_rect[s][3])))
+            continue;
+        float t;
+        if (sphere_ray_intersect_t(ld3(p.spheres[s].center), p.spheres[s].radius, O, D, t)) {
+            const float current_depth = 1.0f - r.depth_tex;  // sphere/compute.wgsl:130
+            const float depth = to_non_linear_depth(t);
+            if (!(depth >= current_depth)) {
+                r.depth_tex = 1.0f - depth;
+                r.obj = -2 - (int32_t)s;
+                r.t = t;
+            }
+        }
+    }
+
+    // -- mesh pass (lib.rs:1174-1184) -----------------------------------------
+    MeshHit best;
+    best.have = false; best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.ndotd = 0.0f; best.idx = 0u;
+    if (p.n_tris) {
+        const float bx0 = (float)blk_x0;
+        const TileRect blk_rect = {bx0, ty0, bx0 + 32.0f, ty0 + 8.0f};
+        const TileRect tile_rect = {tx0, ty0, tx0 + 8.0f, ty0 + 8.0f};
+        for (uint32_t base = 0; base < p.n_tris; base += 256u) {
+            // level 1: 256 faces vs the block rectangle, order-preserving compaction into LDS
+            const uint32_t j = base + threadIdx.x;
+            bool keep = j < p.n_tris;
+            if (CULL && keep) keep = !rect_culls(ftris[j], blk_rect);
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) sh.wave_cnt[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t off = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) {
+                const uint32_t c = sh.wave_cnt[w];
+                off += (w < wave) ? c : 0u;
+                total += c;
+            }
+            total = __builtin_amdgcn_readfirstlane(total);
+            if (COUNT) dbg_listed += total;
+            if (keep) sh.cand[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
+            __syncthreads();
+            // level 2: list entries vs this wave's tile rectangle (skipped for short lists,
+            // where it costs more than the exact tests it saves), then the exact test
+            const bool wave_cull = CULL && total > p.wave_cull_min;
+            for (uint32_t cbase = 0; cbase < total; cbase += 64u) {
+                const uint32_t e = cbase + lane;
+                bool keep2 = e < total;
+                const uint32_t my_idx = keep2 ? sh.cand[e] : 0u;
+                if (wave_cull && keep2) keep2 = !rect_culls(ftris[my_idx], tile_rect);
+                unsigned long long m2 = __ballot(keep2);
+                while (m2) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(m2);
+                    m2 &= m2 - 1ull;
+                    // wave-uniform face index: the record comes in through scalar loads
+                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_idx, (int)b);
+                    intersect_and_select(tris[idx], idx, O, D, best);
+                    if (COUNT) dbg_tested++;
+                }
+            }
+            if (base + 256u < p.n_tris) __syncthreads();  // cand / wave_cnt are rewritten by the next batch
+        }
+    }
+    r.mesh = best;
+    if (best.have) {
+        const float current_depth = 1.0f - r.depth_tex;  // compute.wgsl:210
+        const float depth = to_non_linear_depth(best.t);
+        if (!(depth >= current_depth)) {
+            r.depth_tex = 1.0f - depth;
+            r.obj = (int32_t)best.idx;
+            r.t = best.t;
+        }
+    }
+}
+
+// Local shading E of the winning surface (colour path) -> rgb; alpha is 2.0 on a hit.
+// *albedo (may be null) receives the surface's diffuse reflectance.
+RWR_DEV f3 shade_winner(const FrameParams &p, const PrimaryHit &r, const TriRecord *__restrict__ tris,
+                        const FaceUV *__restrict__ face_uv, const uint32_t *__restrict__ tex, const float *lut, f3 O,
+                        f3 D, f3 *albedo)
+{
+    if (r.obj >= 0) {
+        const TriRecord &T = tris[r.obj];
+        f3 N = ld3(T.N);
+        if (r.mesh.ndotd > 0.0f) N = neg3(N);  // compute.wgsl:140-142
+        return shade_mesh(face_uv[r.obj], r.mesh.u, r.mesh.v, T.denom, N, D, p.ambient, p.specular, tex, p.tex_w, p.tex_h,
+                          lut, albedo);
+    }
+    const uint32_t k = (uint32_t)(-2 - r.obj);
+    const f3 P = along(O, r.t, D);
+    const f3 n = cnormalize(sub3(P, ld3(p.spheres[k].center)));
+    if (albedo) *albedo = mk3(1.0f, 0.0f, 0.0f);
+    return shade_sphere(n, D);
+}
+
+}  // namespace rwr

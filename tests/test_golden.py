@@ -42,10 +42,13 @@ def test_host_camera_reproduces_golden_uniform(rwr, golden):
 
 
 @pytest.mark.gpu
-def test_gpu_reproduces_golden(rwr, gpu_ctx, golden):
+def test_gpu_reproduces_golden(rwr, gpu_ctx, golden, suzanne, cube):
+    # scene arrays come from the loader the golden frames were made with (the cube's JPEG texture
+    # decodes +-2 LSB differently in other decoders; decoder parity is tests/test_host_surface.py)
+    models = {"suzanne_lowpoly.obj": suzanne, "cube.obj": cube}
     for name, g in golden.items():
         w, h = map(int, g["size"])
-        gpu_ctx.upload_model(rwr.load_model_compute(str(g["scene"])))
+        gpu_ctx.upload_model(models[str(g["scene"])])
         gpu_ctx.set_instances(None)
         gpu_ctx.set_spheres(g["spheres"].view(rwr.SPHERE_DTYPE))
         gpu_ctx.resize(w, h)
