@@ -84,7 +84,8 @@ struct rwr_context {
     // wavefront integrator state
     DeviceBuffer<float4> d_accum, d_q0, d_q1;
     DeviceBuffer<float2> d_q2;
-    DeviceBuffer<uint32_t> d_counters;
+    DeviceBuffer<uint32_t> d_seg_count, d_seg_total;
+    uint32_t last_segments = 0;
     uint32_t last_spp = 0;
     bool last_had_bounce = false;
     DeviceBuffer<uint32_t> d_tex;
@@ -333,7 +334,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
     ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
     ctx->d_tris.release(); ctx->d_face_uv.release(); ctx->d_cull.release(); ctx->d_ftris.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
-    ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_counters.release(); ctx->d_tex.release(); ctx->d_lut.release();
+    ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_seg_count.release(); ctx->d_seg_total.release(); ctx->d_tex.release(); ctx->d_lut.release();
     ctx->d_color.release(); ctx->d_depth.release(); ctx->d_color_f32.release();
     ctx->d_obj_id.release(); ctx->d_hit_t.release();
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -525,16 +526,17 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         ctx->last_spp = 0;
     } else {
         // wavefront integrator: per sample pass, primary stage then (queue-driven) bounce stage
-        const size_t band_px = (size_t)ctx->screen.width * (row_end - row_begin);
+        // one 256-slot queue segment per workgroup (32x8 pixels) of the primary stage
+        const uint32_t n_segments = ((ctx->screen.width + 31u) / 32u) * ((row_end - row_begin + 7u) / 8u);
         RWR_HIP_CHECK(ctx->d_accum.ensure(n));
-        RWR_HIP_CHECK(ctx->d_counters.ensure(rp.spp));
+        RWR_HIP_CHECK(ctx->d_seg_count.ensure(n_segments));
+        RWR_HIP_CHECK(ctx->d_seg_total.ensure(n_segments));
         if (rp.max_bounces) {
-            RWR_HIP_CHECK(ctx->d_q0.ensure(band_px));
-            RWR_HIP_CHECK(ctx->d_q1.ensure(band_px));
-            RWR_HIP_CHECK(ctx->d_q2.ensure(band_px));
+            RWR_HIP_CHECK(ctx->d_q0.ensure((size_t)n_segments * 256));
+            RWR_HIP_CHECK(ctx->d_q1.ensure((size_t)n_segments * 256));
+            RWR_HIP_CHECK(ctx->d_q2.ensure((size_t)n_segments * 256));
         }
-        RWR_HIP_CHECK(hipMemsetAsync(ctx->d_counters.ptr, 0, (size_t)rp.spp * sizeof(uint32_t), ctx->stream));
-        const WfBuffers wf{ctx->d_accum.ptr, ctx->d_q0.ptr, ctx->d_q1.ptr, ctx->d_q2.ptr, ctx->d_counters.ptr};
+        const WfBuffers wf{ctx->d_accum.ptr, ctx->d_q0.ptr, ctx->d_q1.ptr, ctx->d_q2.ptr, ctx->d_seg_count.ptr, ctx->d_seg_total.ptr};
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
         for (uint32_t sidx = 0; sidx < rp.spp; sidx++) {
             fp.sample = sidx;
@@ -542,10 +544,11 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
                                             ctx->d_lut.ptr, tg, wf));
             if (rp.max_bounces)
                 RWR_HIP_CHECK(launch_wf_bounce(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, bvh, ctx->d_tex.ptr,
-                                               ctx->d_lut.ptr, wf, (uint32_t)band_px));
+                                               ctx->d_lut.ptr, wf, n_segments));
         }
         RWR_HIP_CHECK(launch_wf_resolve(ctx->stream, fp, tg, wf));
         ctx->last_spp = rp.spp;
+        ctx->last_segments = n_segments;
         ctx->last_had_bounce = rp.max_bounces != 0;
     }
     ctx->aux_valid = aux;
@@ -617,9 +620,9 @@ int rwr_last_render_stats(rwr_context *ctx, uint64_t *primary_rays, uint64_t *bo
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (ctx->last_spp && ctx->last_had_bounce) {
         DeviceGuard g(ctx->device);
-        std::vector<uint32_t> counts(ctx->last_spp);
+        std::vector<uint32_t> counts(ctx->last_segments);
         RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        RWR_HIP_CHECK(hipMemcpy(counts.data(), ctx->d_counters.ptr, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        RWR_HIP_CHECK(hipMemcpy(counts.data(), ctx->d_seg_total.ptr, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         ctx->last_bounce = 0;
         for (uint32_t c : counts) ctx->last_bounce += c;
     }

@@ -113,12 +113,14 @@ hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, co
                           uint32_t n_faces, const rwr_instance_raw *instances, uint32_t n_instances,
                           TriRecord *tris, FaceUV *face_uv, CullRec *cull);
 // Wavefront integrator state (kernels_wavefront.hip).  Ray queue = SoA in HBM, 40 B per
-// bounce ray: q0 = {O.xyz, pixel}, q1 = {D.xyz, thr.r}, q2 = {thr.g, thr.b}.
+// bounce ray: q0 = {O.xyz, pixel}, q1 = {D.xyz, thr.r}, q2 = {thr.g, thr.b}; workgroup w of
+// the primary stage owns slots [256 w, 256 w + seg_count[w]).
 struct WfBuffers {
     float4 *accum;        // W*H RGBA32F running sums (rgb = radiance, a = 2 * primary hits)
     float4 *q0, *q1;
     float2 *q2;
-    uint32_t *counters;   // one per sample pass: bounce rays emitted
+    uint32_t *seg_count;  // per workgroup of k_wf_primary: rays in its 256-slot queue segment (this pass)
+    uint32_t *seg_total;  // per workgroup: bounce rays emitted over all passes of the frame
 };
 struct BvhNode4;
 struct BvhDevice {
@@ -133,7 +135,7 @@ hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriReco
                              const WfBuffers &wf);
 hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
                             const BvhDevice &bvh, const uint32_t *tex, const float *srgb_lut, const WfBuffers &wf,
-                            uint32_t max_rays);
+                            uint32_t n_segments);
 hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf);
 
 hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const CullRec *cull, uint32_t n_tris, FrameTri *ftris);
