@@ -185,7 +185,10 @@ def main() -> int:
     torch.cuda.synchronize()
     barrier()
 
-    # timed region: exactly K steps; HIP events on the launch stream for the kernel time
+    # dominant-kernel duration: HIP events around that kernel alone, on its launch stream, for a
+    # sample of the frames INSIDE the timed region (every 16th frame at most 256 brackets)
+    ctx.set_kernel_timing(max(1, args.steps // 128))
+    # timed region: exactly K steps; HIP events on the launch stream for the whole region
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -197,6 +200,7 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
     barrier()
     dev_ms = ev0.elapsed_time(ev1)
+    kernel_us, kernel_samples = ctx.kernel_timing_stats()
 
     if world > 1:
         t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -214,7 +218,7 @@ def main() -> int:
 
     out = None
     if rank == 0:
-        launch_s = dev_ms * 1e-3 / args.steps
+        launch_s = kernel_us * 1e-6 if kernel_samples else dev_ms * 1e-3 / args.steps
         if cfg["spp"] == 1 and cfg["bounces"] == 0:
             # dominant kernel: k_primary — one launch per step on this rank's band (plus the
             # one-workgroup k_frame_setup that precedes it on the same stream)
@@ -228,10 +232,20 @@ def main() -> int:
             kernel = "k_wf_primary + k_wf_bounce (all sample passes of one frame)"
             note = "96 B per path segment (ray + hit record, written and read) + 20 B per pixel (RGBA32F + RGBA8)"
         achieved = algo_bytes / launch_s / 1e9
+        # HBM bytes per launch from the committed PMC passes (not collectable live inside this process);
+        # only valid for the exact launch they were measured on
+        traffic = None
+        if kernel == "k_primary" and world == 1 and args.config == "cfg2":
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                    traffic = json.load(fh)["k_primary"]["traffic_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                traffic = None
         roofline = {
             "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-            "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(launch_s * 1e6, 3), "note": note,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(launch_s * 1e6, 3),
+            "launch_us_samples": kernel_samples, "step_us_on_stream": round(dev_ms * 1e3 / args.steps, 3), "note": note,
         }
         out = {
             "metric": "Mray/s", "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps,

@@ -201,6 +201,14 @@ RWR_API int rwr_get_device_targets(rwr_context *ctx, void **d_rgba8, void **d_de
 RWR_API int rwr_timer_begin(rwr_context *ctx);
 RWR_API int rwr_timer_end(rwr_context *ctx, float *elapsed_ms); /* synchronises on the end event */
 
+/* Per-kernel timing for roofline accounting: when every_n > 0, every n-th render call
+ * brackets its DOMINANT kernel (k_primary; for the wavefront integrator all sample passes of
+ * the frame) with hipEvents on the launch stream.  rwr_kernel_timing_stats synchronises and
+ * returns the mean duration in microseconds over the brackets recorded since it was enabled
+ * (at most 256 are kept) and their count. */
+RWR_API int rwr_ctx_set_kernel_timing(rwr_context *ctx, uint32_t every_n);
+RWR_API int rwr_kernel_timing_stats(rwr_context *ctx, double *mean_us, uint32_t *count);
+
 /* Segments (rays) traced by the last render call, for Mray/s accounting:
  * W*rows*spp primary + bounce rays actually emitted. */
 RWR_API int rwr_last_render_stats(rwr_context *ctx, uint64_t *primary_rays, uint64_t *bounce_rays);

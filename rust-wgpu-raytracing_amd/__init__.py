@@ -100,6 +100,7 @@ def lib() -> C.CDLL:
         "rwr_decode_image_rgba8": [vp, C.c_size_t, vp, vp, vp], "rwr_free": [vp],
         "rwr_make_instance_grid": [u32, f32, vp],
         "rwr_write_png_rgba8": [C.c_char_p, vp, u32, u32, i32, i32],
+        "rwr_ctx_set_kernel_timing": [vp, u32], "rwr_kernel_timing_stats": [vp, vp, vp],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
@@ -317,6 +318,14 @@ class Context:
         ms = C.c_float()
         _check(lib().rwr_timer_end(self._h, C.byref(ms)))
         return ms.value
+
+    def set_kernel_timing(self, every_n: int):
+        _check(lib().rwr_ctx_set_kernel_timing(self._h, every_n))
+
+    def kernel_timing_stats(self) -> tuple[float, int]:
+        mean, n = C.c_double(), C.c_uint32()
+        _check(lib().rwr_kernel_timing_stats(self._h, C.byref(mean), C.byref(n)))
+        return mean.value, n.value
 
     def last_render_stats(self) -> tuple[int, int]:
         a, b = C.c_uint64(), C.c_uint64()

@@ -108,6 +108,11 @@ struct rwr_context {
     bool aux_valid = false;
 
     uint64_t last_primary = 0, last_bounce = 0;
+    // optional per-kernel timing (rwr_ctx_set_kernel_timing)
+    uint32_t timing_every = 0;
+    uint64_t timing_calls = 0;
+    std::vector<hipEvent_t> timing_events;  // pairs
+    uint32_t timing_pairs = 0;
     uint32_t wave_cull_min = 4;  // tunable: RWR_WAVE_CULL_MIN
 };
 
@@ -337,6 +342,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
     ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_seg_count.release(); ctx->d_seg_total.release(); ctx->d_tex.release(); ctx->d_lut.release();
     ctx->d_color.release(); ctx->d_depth.release(); ctx->d_color_f32.release();
     ctx->d_obj_id.release(); ctx->d_hit_t.release();
+    for (hipEvent_t e : ctx->timing_events) (void)hipEventDestroy(e);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -521,6 +527,17 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         // cross-stream event waits cost more than the kernel.)
         RWR_HIP_CHECK(launch_frame_setup(ctx->stream, cc, ctx->d_cull.ptr, ctx->n_tris, ctx->d_ftris.ptr));
     }
+    const bool time_this = ctx->timing_every && (ctx->timing_calls++ % ctx->timing_every == 0) && ctx->timing_pairs < 256;
+    if (time_this) {
+        if (ctx->timing_events.size() < 2u * (ctx->timing_pairs + 1u)) {
+            hipEvent_t a, b;
+            RWR_HIP_CHECK(hipEventCreate(&a));
+            RWR_HIP_CHECK(hipEventCreate(&b));
+            ctx->timing_events.push_back(a);
+            ctx->timing_events.push_back(b);
+        }
+        RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs], ctx->stream));
+    }
     if (!wavefront) {
         RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, ctx->d_lut.ptr, tg));
         ctx->last_spp = 0;
@@ -550,6 +567,10 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         ctx->last_spp = rp.spp;
         ctx->last_segments = n_segments;
         ctx->last_had_bounce = rp.max_bounces != 0;
+    }
+    if (time_this) {
+        RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs + 1], ctx->stream));
+        ctx->timing_pairs++;
     }
     ctx->aux_valid = aux;
     ctx->last_primary = (uint64_t)ctx->screen.width * (row_end - row_begin) * rp.spp;
@@ -612,6 +633,31 @@ int rwr_timer_end(rwr_context *ctx, float *elapsed_ms)
     RWR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
     RWR_HIP_CHECK(hipEventSynchronize(ctx->ev_end));
     RWR_HIP_CHECK(hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
+    return RWR_OK;
+}
+
+int rwr_ctx_set_kernel_timing(rwr_context *ctx, uint32_t every_n)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    ctx->timing_every = every_n;
+    ctx->timing_calls = 0;
+    ctx->timing_pairs = 0;
+    return RWR_OK;
+}
+
+int rwr_kernel_timing_stats(rwr_context *ctx, double *mean_us, uint32_t *count)
+{
+    if (!ctx || !mean_us || !count) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double sum = 0.0;
+    for (uint32_t i = 0; i < ctx->timing_pairs; i++) {
+        float ms = 0.0f;
+        RWR_HIP_CHECK(hipEventElapsedTime(&ms, ctx->timing_events[2 * i], ctx->timing_events[2 * i + 1]));
+        sum += ms * 1e3;
+    }
+    *count = ctx->timing_pairs;
+    *mean_us = ctx->timing_pairs ? sum / ctx->timing_pairs : 0.0;
     return RWR_OK;
 }
 
