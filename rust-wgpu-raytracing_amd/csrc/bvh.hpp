@@ -32,7 +32,7 @@ static_assert(sizeof(BvhNode4) == 128, "BvhNode4 is 128 B");
 
 constexpr uint32_t kBvhEmpty = 0xffffffffu;
 constexpr uint32_t kBvhLeafBit = 0x80000000u;
-constexpr uint32_t kBvhMaxLeaf = 2;  // the exact hit test costs ~4x a box test: prefer small leaves
+constexpr uint32_t kBvhMaxLeafDefault = 2;  // the exact hit test costs ~4x a box test: prefer small leaves
 
 struct Bvh {
     std::vector<BvhNode4> nodes;       // nodes[0] is the root (present even for 1 face)
@@ -71,6 +71,7 @@ struct Node2 {
 
 struct Builder {
     const float *tri;  // n x 9 floats (p0, p1, p2)
+    uint32_t max_leaf = kBvhMaxLeafDefault;
     std::vector<Box> tbox;
     std::vector<float> cen;  // n x 3
     std::vector<uint32_t> order;
@@ -88,7 +89,7 @@ struct Builder {
         }
         const int self = (int)nodes.size();
         nodes.push_back(node);
-        if (count <= kBvhMaxLeaf) {
+        if (count <= max_leaf) {
             nodes[self].first = first;
             nodes[self].count = count;
             return self;
@@ -157,12 +158,13 @@ struct Builder {
 }  // namespace bvh_detail
 
 // tri: n faces x 9 floats (world-space p0, p1, p2 as the device holds them).
-inline Bvh build_bvh(const float *tri, uint32_t n)
+inline Bvh build_bvh(const float *tri, uint32_t n, uint32_t max_leaf = kBvhMaxLeafDefault)
 {
     using namespace bvh_detail;
     Bvh out;
     Builder b;
     b.tri = tri;
+    b.max_leaf = std::min(std::max(max_leaf, 1u), 8u);
     b.tbox.resize(n);
     b.cen.resize((size_t)3 * n);
     b.order.resize(n);

@@ -162,8 +162,8 @@ k_wf_bounce(const FrameParams p, const TriRecord *__restrict__ tris, const FaceU
     MeshHit mh;
     mh.have = false; mh.t = 0.0f; mh.u = 0.0f; mh.v = 0.0f; mh.ndotd = 0.0f; mh.idx = 0u;
     if (p.n_tris) {
-        if (NODES_IN_LDS) bvh_nearest(s_nodes, bvh.leaf_faces, tris, s_stack, O, D, mh);
-        else bvh_nearest(bvh.nodes, bvh.leaf_faces, tris, s_stack, O, D, mh);
+        if (NODES_IN_LDS) bvh_nearest(s_nodes, bvh.leaf_faces, tris, p.n_tris, s_stack, O, D, mh);
+        else bvh_nearest(bvh.nodes, bvh.leaf_faces, tris, p.n_tris, s_stack, O, D, mh);
         if (mh.have && (!have || mh.t < best_t)) { have = true; best_t = mh.t; obj = (int32_t)mh.idx; }
     }
     if (!have) return;
