@@ -107,6 +107,8 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the gather path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.steps is None:
@@ -131,10 +133,12 @@ def main() -> int:
         return 2
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist  # backend "nccl" is RCCL on ROCm
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from rwr_amd.partition import band_rows, gather_bands_equal, gather_bands_ragged, make_gather_list
@@ -161,7 +165,7 @@ def main() -> int:
 
     band = None
     gather_list = None
-    if world > 1:
+    if use_dist:
         d_color, _ = ctx.device_targets()
         band = torch.as_tensor(_DevArray(d_color + r0 * w * 4, (r1 - r0) * w * 4), device=f"cuda:{local_rank}")
         if rank == 0:
@@ -173,11 +177,11 @@ def main() -> int:
 
     def step():
         render()
-        if world > 1:
+        if use_dist:
             gather(dist, band, gather_list, rank, 0)   # the frame's single collective (RCCL over xGMI)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -202,7 +206,7 @@ def main() -> int:
     dev_ms = ev0.elapsed_time(ev1)
     kernel_us, kernel_samples = ctx.kernel_timing_stats()
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
@@ -210,12 +214,18 @@ def main() -> int:
     # path segments actually traced: W*H*spp primary rays + the bounce rays the queue carried
     primary_rays, bounce_rays = ctx.last_render_stats()
     seg = torch.tensor([primary_rays + bounce_rays], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(seg, op=dist.ReduceOp.SUM)
     rays_per_frame = float(seg[0])
     ms_per_step = elapsed * 1e3 / args.steps
     value = rays_per_frame / (elapsed / args.steps) / 1e6
 
+    gathered_ok = None
+    if use_dist and rank == 0:
+        # the gathered frame must equal what a single GPU renders (checked once, outside the timed region)
+        torch.cuda.synchronize()
+        got = frame.cpu().numpy().reshape(h, w, 4)
+        gathered_ok = bool(got.any()) and (world > 1 or bool((got == ctx.readback()["color"]).all()))
     out = None
     if rank == 0:
         launch_s = kernel_us * 1e-6 if kernel_samples else dev_ms * 1e-3 / args.steps
@@ -256,8 +266,10 @@ def main() -> int:
                        "device": info["name"]},
             "roofline": roofline,
         }
+        if gathered_ok is not None:
+            out["config"]["gathered_frame_ok"] = gathered_ok
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if rank == 0:
         if world == 1 and args.cpu_seconds > 0:
