@@ -77,6 +77,8 @@ struct rwr_context {
     DeviceBuffer<FaceUV> d_face_uv;
     DeviceBuffer<CullRec> d_cull;
     DeviceBuffer<FrameTri> d_ftris;
+    DeviceBuffer<uint32_t> d_bin_lists, d_bin_counts;   // per-frame screen bins (large scenes)
+    uint32_t bin_min_faces = 256;                       // tunable: RWR_BIN_MIN_FACES
     // BVH over the (flattened) world-space faces, for bounce rays
     DeviceBuffer<BvhNode4> d_bvh_nodes;
     DeviceBuffer<uint32_t> d_bvh_leaf_faces;
@@ -322,6 +324,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     }
     ctx->stream = ctx->own_stream;
     if (const char *e2 = std::getenv("RWR_WAVE_CULL_MIN")) ctx->wave_cull_min = (uint32_t)std::strtoul(e2, nullptr, 10);
+    if (const char *e3 = std::getenv("RWR_BIN_MIN_FACES")) ctx->bin_min_faces = (uint32_t)std::strtoul(e3, nullptr, 10);
     float lut[256];
     build_srgb_lut(lut);
     if ((e = ctx->d_lut.ensure(256)) != hipSuccess ||
@@ -339,7 +342,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
     DeviceGuard g(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
-    ctx->d_tris.release(); ctx->d_face_uv.release(); ctx->d_cull.release(); ctx->d_ftris.release();
+    ctx->d_tris.release(); ctx->d_face_uv.release(); ctx->d_cull.release(); ctx->d_ftris.release(); ctx->d_bin_lists.release(); ctx->d_bin_counts.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
     ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_seg_count.release(); ctx->d_seg_total.release(); ctx->d_tex.release(); ctx->d_lut.release();
     ctx->d_color.release(); ctx->d_depth.release(); ctx->d_color_f32.release();
@@ -528,6 +531,15 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         // previous frame, was measured 4-10 us SLOWER per frame than the 3 us it hides:
         // cross-stream event waits cost more than the kernel.)
         RWR_HIP_CHECK(launch_frame_setup(ctx->stream, cc, ctx->d_cull.ptr, ctx->n_tris, ctx->d_ftris.ptr));
+        if (ctx->n_tris > ctx->bin_min_faces) {
+            // more faces than one 256-wide batch: bin them per 64x32-pixel screen region, once per frame
+            const uint32_t bins_x = (ctx->screen.width + kBinW - 1) / kBinW, bins_y = (row_end - row_begin + kBinH - 1) / kBinH;
+            RWR_HIP_CHECK(ctx->d_bin_lists.ensure((size_t)bins_x * bins_y * ctx->n_tris));
+            RWR_HIP_CHECK(ctx->d_bin_counts.ensure((size_t)bins_x * bins_y));
+            RWR_HIP_CHECK(launch_bin_faces(ctx->stream, ctx->d_ftris.ptr, ctx->n_tris, row_begin, ctx->d_bin_lists.ptr,
+                                           ctx->d_bin_counts.ptr, bins_x, bins_y, ctx->n_tris));
+            fp.bins = BinGrid{ctx->d_bin_lists.ptr, ctx->d_bin_counts.ptr, bins_x, bins_y, ctx->n_tris, 1u};
+        }
     }
     const bool time_this = ctx->timing_every && (ctx->timing_calls++ % ctx->timing_every == 0) && ctx->timing_pairs < 256;
     if (time_this) {

@@ -120,6 +120,51 @@ hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const CullRec
 }
 
 // ---------------------------------------------------------------------------
+// Per-frame screen binning: one workgroup per 64x32-pixel bin walks all faces 256 at a time
+// and writes the ascending list of those its rectangle cannot reject (same ballot + prefix
+// compaction as the render kernels' block level, so lists stay in face order and the
+// lowest-index tie rule survives).
+__global__ void __launch_bounds__(256)
+k_bin_faces(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *__restrict__ lists,
+            uint32_t *__restrict__ counts, uint32_t bins_x, uint32_t cap)
+{
+    __shared__ uint32_t s_cnt[4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t bin = blockIdx.y * bins_x + blockIdx.x;
+    const float x0 = (float)(blockIdx.x * kBinW), y0 = (float)(row_begin + blockIdx.y * kBinH);
+    const TileRect rect = {x0, y0, x0 + (float)kBinW, y0 + (float)kBinH};
+    uint32_t *__restrict__ out = lists + (size_t)bin * cap;
+    uint32_t written = 0;
+    for (uint32_t base = 0; base < n_tris; base += 256u) {
+        const uint32_t j = base + threadIdx.x;
+        bool keep = j < n_tris;
+        if (keep) keep = !rect_culls(ftris[j], rect);
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++) {
+            const uint32_t c = s_cnt[w];
+            off += (w < wave) ? c : 0u;
+            total += c;
+        }
+        if (keep) out[written + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;  // written + total <= n_tris <= cap
+        written += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[bin] = written;
+}
+
+hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *lists,
+                            uint32_t *counts, uint32_t bins_x, uint32_t bins_y, uint32_t cap)
+{
+    if (n_tris == 0 || bins_x == 0 || bins_y == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bin_faces, dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts, bins_x, cap);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 template <bool AUX, bool CULL>
 __global__ void __launch_bounds__(256, 8)  // 8 waves per SIMD: <= 64 VGPRs
 k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,

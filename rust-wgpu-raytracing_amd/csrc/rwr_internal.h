@@ -86,8 +86,20 @@ struct alignas(16) FrameTri {
 };
 static_assert(sizeof(FrameTri) == 64, "FrameTri is 64 B");
 
+// Per-frame screen bins (kernels_primary.hip k_bin_faces): for scenes with more faces than one
+// 256-wide batch, every 64x32-pixel bin (= 2x4 workgroups of the render kernels) gets the
+// ascending list of faces that can be seen through it, so a workgroup walks its bin's list
+// instead of the whole scene.  Built once per frame, shared by all sample passes.
+constexpr uint32_t kBinW = 64, kBinH = 32;
+struct BinGrid {
+    const uint32_t *lists;   // bins * cap face indices
+    const uint32_t *counts;  // bins
+    uint32_t bins_x, bins_y, cap, enabled;
+};
+
 struct FrameParams {
     rwr_camera_inv_uniform cam;
+    BinGrid bins;
     uint32_t width, height;       // full frame
     uint32_t row_begin, row_end;  // band rendered by this launch
     uint32_t n_spheres;
@@ -139,6 +151,8 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
 hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf);
 
 hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const CullRec *cull, uint32_t n_tris, FrameTri *ftris);
+hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *lists,
+                            uint32_t *counts, uint32_t bins_x, uint32_t bins_y, uint32_t cap);
 hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
                           const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg);
 

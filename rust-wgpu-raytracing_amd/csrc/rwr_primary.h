@@ -63,10 +63,20 @@ RWR_DEV void primary_visibility(const FrameParams &p, const TriRecord *__restric
         const float bx0 = (float)blk_x0;
         const TileRect blk_rect = {bx0, ty0, bx0 + 32.0f, ty0 + 8.0f};
         const TileRect tile_rect = {tx0, ty0, tx0 + 8.0f, ty0 + 8.0f};
-        for (uint32_t base = 0; base < p.n_tris; base += 256u) {
+        // source of candidate faces: the whole scene, or this workgroup's screen bin
+        uint32_t n_src = p.n_tris;
+        const uint32_t *__restrict__ src = nullptr;
+        if (CULL && p.bins.enabled) {
+            const uint32_t bin = ((tile_y0 - p.row_begin) / kBinH) * p.bins.bins_x + blk_x0 / kBinW;
+            n_src = p.bins.counts[bin];
+            src = p.bins.lists + (size_t)bin * p.bins.cap;
+        }
+        n_src = __builtin_amdgcn_readfirstlane(n_src);
+        for (uint32_t base = 0; base < n_src; base += 256u) {
             // level 1: 256 faces vs the block rectangle, order-preserving compaction into LDS
-            const uint32_t j = base + threadIdx.x;
-            bool keep = j < p.n_tris;
+            const uint32_t e0 = base + threadIdx.x;
+            bool keep = e0 < n_src;
+            const uint32_t j = (keep && src) ? src[e0] : e0;
             if (CULL && keep) keep = !rect_culls(ftris[j], blk_rect);
             const unsigned long long m = __ballot(keep);
             if (lane == 0) sh.wave_cnt[wave] = (uint32_t)__popcll(m);
@@ -100,7 +110,7 @@ RWR_DEV void primary_visibility(const FrameParams &p, const TriRecord *__restric
                     if (COUNT) dbg_tested++;
                 }
             }
-            if (base + 256u < p.n_tris) __syncthreads();  // cand / wave_cnt are rewritten by the next batch
+            if (base + 256u < n_src) __syncthreads();  // cand / wave_cnt are rewritten by the next batch
         }
     }
     r.mesh = best;
