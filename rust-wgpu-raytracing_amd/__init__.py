@@ -38,6 +38,8 @@ assert (CAMERA_INV_DTYPE.itemsize, VERTEX_DTYPE.itemsize, FACE_DTYPE.itemsize, M
         SPHERE_DTYPE.itemsize, INSTANCE_DTYPE.itemsize, CAMERA_DTYPE.itemsize) == (144, 32, 16, 48, 16, 64, 52)
 
 FLAG_AUX_OUTPUTS, FLAG_NO_CULL, FLAG_USE_BVH = 1, 2, 4
+# internal debug flags (csrc/rwr_internal.h, not part of include/rwr_hip.h)
+FLAG_DEBUG_COUNTS, FLAG_ONE_PIXEL_PER_LANE = 1 << 16, 1 << 17
 KEY_FORWARD, KEY_BACKWARD, KEY_LEFT, KEY_RIGHT, KEY_UP, KEY_DOWN = 1, 2, 4, 8, 16, 32
 OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NOT_READY, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 

@@ -79,6 +79,7 @@ struct rwr_context {
     DeviceBuffer<FrameTri> d_ftris;
     DeviceBuffer<uint32_t> d_bin_lists, d_bin_counts;   // per-frame screen bins (large scenes)
     uint32_t bin_min_faces = 256;                       // tunable: RWR_BIN_MIN_FACES
+    bool force_one_pixel = false;                       // debug: RWR_ONE_PIXEL_PER_LANE=1
     // BVH over the (flattened) world-space faces, for bounce rays
     DeviceBuffer<BvhNode4> d_bvh_nodes;
     DeviceBuffer<uint32_t> d_bvh_leaf_faces;
@@ -324,6 +325,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     }
     ctx->stream = ctx->own_stream;
     if (const char *e2 = std::getenv("RWR_WAVE_CULL_MIN")) ctx->wave_cull_min = (uint32_t)std::strtoul(e2, nullptr, 10);
+    if (const char *e4 = std::getenv("RWR_ONE_PIXEL_PER_LANE")) ctx->force_one_pixel = std::atoi(e4) != 0;
     if (const char *e3 = std::getenv("RWR_BIN_MIN_FACES")) ctx->bin_min_faces = (uint32_t)std::strtoul(e3, nullptr, 10);
     float lut[256];
     build_srgb_lut(lut);
@@ -553,7 +555,10 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs], ctx->stream));
     }
     if (!wavefront) {
-        RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, ctx->d_lut.ptr, tg));
+        if ((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel)
+            RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, ctx->d_lut.ptr, tg));
+        else
+            RWR_HIP_CHECK(launch_primary_p2(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, ctx->d_lut.ptr, tg));
         ctx->last_spp = 0;
     } else {
         // wavefront integrator: per sample pass, primary stage then (queue-driven) bounce stage

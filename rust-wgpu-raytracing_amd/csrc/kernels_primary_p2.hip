@@ -1,0 +1,189 @@
+// Fused frame kernel, two pixels per lane (see rwr_device_p2.h for why).  Same algorithm and
+// same results as kernels_primary.hip's k_primary — which stays as the one-pixel-per-lane
+// form (RWR_FLAG_ONE_PIXEL_PER_LANE, narrow frames, and the wavefront integrator's first
+// stage) — with this mapping:
+//   wave64  = 16x8 pixel tile, lane l owns pixels (2*(l&7), l>>3) and (2*(l&7)+1, l>>3);
+//   workgroup (4 waves) = 64x8 pixels = one screen-bin column (kBinW), so a row of the
+//   RGBA8 / R32F targets is written as 256 contiguous bytes by one workgroup, 8 B per lane.
+#include "rwr_device_p2.h"
+#include "rwr_primary.h"
+
+namespace rwr {
+
+template <bool AUX, bool CULL>
+__global__ void __launch_bounds__(256, 8)
+k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
+             const FrameTri *__restrict__ ftris, const uint32_t *__restrict__ tex, const float *__restrict__ srgb_lut,
+             const Targets tg)
+{
+    __shared__ float s_lut[256];
+    __shared__ PrimaryShared sh;
+    s_lut[threadIdx.x] = srgb_lut[threadIdx.x];
+
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t blk_x0 = blockIdx.x * 64u;
+    const uint32_t tile_x0 = blk_x0 + wave * 16u;
+    const uint32_t tile_y0 = p.row_begin + blockIdx.y * 8u;
+    const uint32_t px0 = tile_x0 + 2u * (lane & 7u), py = tile_y0 + (lane >> 3);
+
+    const f3 O = ld3(p.cam.origin);
+    const v3 D = pixel_pair_ray_dir(p.cam, px0, py, p.width, p.height);
+
+    // framebuffer state of the two pixels, as the reference's cleared textures hold it
+    f2 depth_tex = splat(0.0f), win_t = splat(0.0f);
+    i2 obj = i2{-1, -1};
+
+    // -- analytic sphere passes, in order (lib.rs:1106-1173) -----------------
+    const float tx0 = (float)tile_x0, ty0 = (float)tile_y0;
+    for (uint32_t s = 0; s < p.n_spheres; s++) {
+        if (CULL && ((tx0 + 16.0f < p.sphere_rect[s][0]) || (tx0 > p.sphere_rect[s][2]) ||
+                     (ty0 + 8.0f < p.sphere_rect[s][1]) || (ty0 > p.sphere_rect[s][3])))
+            continue;
+        f2 t = splat(0.0f);
+        const i2 hit = sphere_ray_intersect_t(ld3(p.spheres[s].center), p.spheres[s].radius, O, D, t);
+        if (any2(hit)) {
+            const f2 current_depth = 1.0f - depth_tex;  // sphere/compute.wgsl:130
+            const f2 depth = to_non_linear_depth(t);
+            const i2 win = hit & ~(depth >= current_depth);
+            depth_tex = win ? (1.0f - depth) : depth_tex;
+            obj = win ? i2{-2 - (int)s, -2 - (int)s} : obj;
+            win_t = win ? t : win_t;
+        }
+    }
+
+    // -- mesh pass (lib.rs:1174-1184) -----------------------------------------
+    MeshHit2 best;
+    best.have = i2{0, 0};
+    best.t = best.u = best.v = best.ndotd = splat(0.0f);
+    best.idx = u2{0u, 0u};
+    uint32_t dbg_listed = 0, dbg_tested = 0;
+    if (p.n_tris) {
+        const float bx0 = (float)blk_x0;
+        const TileRect blk_rect = {bx0, ty0, bx0 + 64.0f, ty0 + 8.0f};
+        const TileRect tile_rect = {tx0, ty0, tx0 + 16.0f, ty0 + 8.0f};
+        uint32_t n_src = p.n_tris;
+        const uint32_t *__restrict__ src = nullptr;
+        if (CULL && p.bins.enabled) {
+            const uint32_t bin = ((tile_y0 - p.row_begin) / kBinH) * p.bins.bins_x + blk_x0 / kBinW;
+            n_src = p.bins.counts[bin];
+            src = p.bins.lists + (size_t)bin * p.bins.cap;
+        }
+        n_src = __builtin_amdgcn_readfirstlane(n_src);
+        for (uint32_t base = 0; base < n_src; base += 256u) {
+            // level 1: 256 faces vs the block rectangle, order-preserving compaction into LDS
+            const uint32_t e0 = base + threadIdx.x;
+            bool keep = e0 < n_src;
+            const uint32_t j = (keep && src) ? src[e0] : e0;
+            if (CULL && keep) keep = !rect_culls(ftris[j], blk_rect);
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) sh.wave_cnt[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t off = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) {
+                const uint32_t c = sh.wave_cnt[w];
+                off += (w < wave) ? c : 0u;
+                total += c;
+            }
+            total = __builtin_amdgcn_readfirstlane(total);
+            if (AUX) dbg_listed += total;
+            if (keep) sh.cand[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
+            __syncthreads();
+            // level 2: list entries vs this wave's tile rectangle, then the exact test on both pixels
+            const bool wave_cull = CULL && total > p.wave_cull_min;
+            for (uint32_t cbase = 0; cbase < total; cbase += 64u) {
+                const uint32_t e = cbase + lane;
+                bool keep2 = e < total;
+                const uint32_t my_idx = keep2 ? sh.cand[e] : 0u;
+                if (wave_cull && keep2) keep2 = !rect_culls(ftris[my_idx], tile_rect);
+                unsigned long long m2 = __ballot(keep2);
+                while (m2) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(m2);
+                    m2 &= m2 - 1ull;
+                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_idx, (int)b);  // wave-uniform
+                    intersect_and_select(tris[idx], idx, O, D, best);
+                    if (AUX) dbg_tested++;
+                }
+            }
+            if (base + 256u < n_src) __syncthreads();
+        }
+    } else {
+        __syncthreads();  // s_lut
+    }
+    if (any2(best.have)) {
+        const f2 current_depth = 1.0f - depth_tex;  // compute.wgsl:210
+        const f2 depth = to_non_linear_depth(best.t);
+        const i2 win = best.have & ~(depth >= current_depth);
+        depth_tex = win ? (1.0f - depth) : depth_tex;
+        obj = win ? i2{(int)best.idx.x, (int)best.idx.y} : obj;
+        win_t = win ? best.t : win_t;
+    }
+
+    // -- shade the winners and store --------------------------------------------
+    uint32_t rgba[2];
+    float4 cf[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        PrimaryHit r;
+        r.depth_tex = k ? depth_tex.y : depth_tex.x;
+        r.obj = k ? obj.y : obj.x;
+        r.t = k ? win_t.y : win_t.x;
+        r.mesh.have = true;
+        r.mesh.t = r.t;
+        r.mesh.u = k ? best.u.y : best.u.x;
+        r.mesh.v = k ? best.v.y : best.v.x;
+        r.mesh.ndotd = k ? best.ndotd.y : best.ndotd.x;
+        r.mesh.idx = k ? best.idx.y : best.idx.x;
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;  // untouched pixels keep the clear value
+        if (r.obj != -1) {
+            const f3 c = shade_winner(p, r, tris, face_uv, tex, s_lut, O, lane3(D, k), nullptr);
+            cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
+        }
+        rgba[k] = pack_rgba8(cr, cg, cb, ca);
+        cf[k] = make_float4(cr, cg, cb, ca);
+    }
+
+    if (py < p.row_end && px0 < p.width) {
+        const size_t o = (size_t)py * p.width + px0;
+        const bool both = px0 + 1u < p.width;
+        const bool dbg = AUX && (p.flags & RWR_FLAG_DEBUG_COUNTS) != 0;
+        if (both && (o & 1u) == 0u) {  // 8-byte aligned pair (always, when the width is even)
+            *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(tg.color) + o) = make_uint2(rgba[0], rgba[1]);
+            *reinterpret_cast<float2 *>(tg.depth + o) = make_float2(depth_tex.x, depth_tex.y);
+        } else {
+            reinterpret_cast<uint32_t *>(tg.color)[o] = rgba[0];
+            tg.depth[o] = depth_tex.x;
+            if (both) {
+                reinterpret_cast<uint32_t *>(tg.color)[o + 1] = rgba[1];
+                tg.depth[o + 1] = depth_tex.y;
+            }
+        }
+        if (AUX) {
+            reinterpret_cast<float4 *>(tg.color_f32)[o] = cf[0];
+            tg.obj_id[o] = dbg ? (int32_t)dbg_listed : obj.x;
+            tg.hit_t[o] = dbg ? (float)dbg_tested : win_t.x;
+            if (both) {
+                reinterpret_cast<float4 *>(tg.color_f32)[o + 1] = cf[1];
+                tg.obj_id[o + 1] = dbg ? (int32_t)dbg_listed : obj.y;
+                tg.hit_t[o + 1] = dbg ? (float)dbg_tested : win_t.y;
+            }
+        }
+    }
+}
+
+hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+                             const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg)
+{
+    if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
+    const dim3 grid((fp.width + 63u) / 64u, (fp.row_end - fp.row_begin + 7u) / 8u);
+    const dim3 block(256);
+    const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
+    const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
+    if (aux && do_cull) hipLaunchKernelGGL((k_primary_p2<true, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
+    else if (aux) hipLaunchKernelGGL((k_primary_p2<true, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
+    else if (do_cull) hipLaunchKernelGGL((k_primary_p2<false, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
+    else hipLaunchKernelGGL((k_primary_p2<false, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
+    return hipGetLastError();
+}
+
+}  // namespace rwr

@@ -13,6 +13,9 @@ namespace rwr {
 // obj_id plane receives the number of block-level candidate faces and the hit_t
 // plane the number of faces the pixel's wave ran the exact test on.
 constexpr uint32_t RWR_FLAG_DEBUG_COUNTS = 1u << 16;
+// Internal: render frames with the one-pixel-per-lane kernel (k_primary) instead of the
+// two-pixels-per-lane one (k_primary_p2); both must give identical results.
+constexpr uint32_t RWR_FLAG_ONE_PIXEL_PER_LANE = 1u << 17;
 
 // ---------------------------------------------------------------------------
 // Device-side scene records (data layout in HBM, see DESIGN.md §"Data layout").
@@ -142,6 +145,8 @@ struct BvhDevice {
     uint32_t stack_depth;  // 3 * tree depth + 2
 };
 
+hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+                             const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg);
 hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
                              const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg,
                              const WfBuffers &wf);

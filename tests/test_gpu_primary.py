@@ -138,3 +138,17 @@ def test_full_size_config2_properties(rwr, orc, gpu_ctx, suzanne):
     np.testing.assert_allclose(mean, (0.12034, 0.07311, 0.06953), atol=2e-5)
     want = orc.render_frame(cam_inv.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), orc.make_spheres(), suzanne)
     _assert_parity(got, want)
+
+
+def test_two_pixel_and_one_pixel_kernels_agree(rwr, gpu_ctx, suzanne, cube):
+    """k_primary_p2 (two pixels per lane, packed f32) and k_primary (one pixel per lane) run the same
+    operation sequence per pixel: every plane must be bit-identical, odd widths included."""
+    cases = [(suzanne, CAMERAS["reference_default_inside_mesh"], (321, 97)), (suzanne, CAMERAS["s_x15_outside"], (130, 67)),
+             (suzanne, CAMERAS["spheres_visible"], (64, 64)), (cube, dict(eye=(2.2, 1.7, 3.1), target=(0, 0, 0)), (99, 50)),
+             (cube, dict(eye=(0, 0, 0), target=(0, 0, -1)), (1, 9)), (suzanne, CAMERAS["oblique"], (15, 3))]
+    for model, cam_kw, (w, h) in cases:
+        cam_inv = rwr.camera_build_inv_uniform(rwr.make_camera(aspect=w / h, **cam_kw))
+        a = _render_gpu(rwr, gpu_ctx, model, rwr.make_spheres(), cam_inv, w, h)
+        b = _render_gpu(rwr, gpu_ctx, model, rwr.make_spheres(), cam_inv, w, h, flags=rwr.FLAG_ONE_PIXEL_PER_LANE)
+        for k in a:
+            assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), (w, h, k)
