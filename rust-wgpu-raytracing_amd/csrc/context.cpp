@@ -91,8 +91,7 @@ struct rwr_context {
     uint32_t last_segments = 0;
     uint32_t last_spp = 0;
     bool last_had_bounce = false;
-    DeviceBuffer<uint32_t> d_tex;
-    DeviceBuffer<float> d_lut;
+    DeviceBuffer<float4> d_tex;   // texels decoded to linear f32 at upload (Rgba8UnormSrgb semantics)
     uint32_t n_verts = 0, n_faces = 0, n_instances = 0, n_tris = 0;
     uint32_t tex_w = 0, tex_h = 0;
     rwr_material_data material{};
@@ -327,13 +326,6 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     if (const char *e2 = std::getenv("RWR_WAVE_CULL_MIN")) ctx->wave_cull_min = (uint32_t)std::strtoul(e2, nullptr, 10);
     if (const char *e4 = std::getenv("RWR_ONE_PIXEL_PER_LANE")) ctx->force_one_pixel = std::atoi(e4) != 0;
     if (const char *e3 = std::getenv("RWR_BIN_MIN_FACES")) ctx->bin_min_faces = (uint32_t)std::strtoul(e3, nullptr, 10);
-    float lut[256];
-    build_srgb_lut(lut);
-    if ((e = ctx->d_lut.ensure(256)) != hipSuccess ||
-        (e = hipMemcpy(ctx->d_lut.ptr, lut, sizeof lut, hipMemcpyHostToDevice)) != hipSuccess) {
-        rwr_ctx_destroy(ctx);
-        return set_error(RWR_ERR_HIP, "sRGB table upload failed: %s", hipGetErrorString(e));
-    }
     *out_ctx = ctx;
     return RWR_OK;
 }
@@ -346,7 +338,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
     ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
     ctx->d_tris.release(); ctx->d_face_uv.release(); ctx->d_cull.release(); ctx->d_ftris.release(); ctx->d_bin_lists.release(); ctx->d_bin_counts.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
-    ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_seg_count.release(); ctx->d_seg_total.release(); ctx->d_tex.release(); ctx->d_lut.release();
+    ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_seg_count.release(); ctx->d_seg_total.release(); ctx->d_tex.release();
     ctx->d_color.release(); ctx->d_depth.release(); ctx->d_color_f32.release();
     ctx->d_obj_id.release(); ctx->d_hit_t.release();
     for (hipEvent_t e : ctx->timing_events) (void)hipEventDestroy(e);
@@ -416,7 +408,15 @@ int rwr_scene_upload_mesh(rwr_context *ctx, const rwr_model_vertex_small *verts,
     RWR_HIP_CHECK(ctx->d_tex.ensure((size_t)tex_w * tex_h));
     RWR_HIP_CHECK(hipMemcpy(ctx->d_verts.ptr, verts, (size_t)n_verts * sizeof *verts, hipMemcpyHostToDevice));
     RWR_HIP_CHECK(hipMemcpy(ctx->d_faces.ptr, faces, (size_t)n_faces * sizeof *faces, hipMemcpyHostToDevice));
-    RWR_HIP_CHECK(hipMemcpy(ctx->d_tex.ptr, rgba8_srgb, (size_t)tex_w * tex_h * 4, hipMemcpyHostToDevice));
+    {
+        float lut[256];
+        build_srgb_lut(lut);
+        std::vector<float4> lin((size_t)tex_w * tex_h);
+        for (size_t i = 0; i < lin.size(); i++)
+            lin[i] = make_float4(lut[rgba8_srgb[4 * i]], lut[rgba8_srgb[4 * i + 1]], lut[rgba8_srgb[4 * i + 2]],
+                                 (float)rgba8_srgb[4 * i + 3] / 255.0f);  // alpha is linear in sRGB formats
+        RWR_HIP_CHECK(hipMemcpy(ctx->d_tex.ptr, lin.data(), lin.size() * sizeof(float4), hipMemcpyHostToDevice));
+    }
     ctx->material = *material;
     ctx->tex_w = tex_w;
     ctx->tex_h = tex_h;
@@ -556,9 +556,9 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     }
     if (!wavefront) {
         if ((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel)
-            RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, ctx->d_lut.ptr, tg));
+            RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, tg));
         else
-            RWR_HIP_CHECK(launch_primary_p2(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, ctx->d_lut.ptr, tg));
+            RWR_HIP_CHECK(launch_primary_p2(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, tg));
         ctx->last_spp = 0;
     } else {
         // wavefront integrator: per sample pass, primary stage then (queue-driven) bounce stage
@@ -577,10 +577,10 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         for (uint32_t sidx = 0; sidx < rp.spp; sidx++) {
             fp.sample = sidx;
             RWR_HIP_CHECK(launch_wf_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr,
-                                            ctx->d_lut.ptr, tg, wf));
+                                            tg, wf));
             if (rp.max_bounces)
                 RWR_HIP_CHECK(launch_wf_bounce(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, bvh, ctx->d_tex.ptr,
-                                               ctx->d_lut.ptr, wf, n_segments));
+                                               wf, n_segments));
         }
         RWR_HIP_CHECK(launch_wf_resolve(ctx->stream, fp, tg, wf));
         ctx->last_spp = rp.spp;

@@ -168,12 +168,10 @@ hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tri
 template <bool AUX, bool CULL>
 __global__ void __launch_bounds__(256, 8)  // 8 waves per SIMD: <= 64 VGPRs
 k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
-          const FrameTri *__restrict__ ftris, const uint32_t *__restrict__ tex, const float *__restrict__ srgb_lut,
+          const FrameTri *__restrict__ ftris, const float4 *__restrict__ tex,
           const Targets tg)
 {
-    __shared__ float s_lut[256];
     __shared__ PrimaryShared s_prim;
-    s_lut[threadIdx.x] = srgb_lut[threadIdx.x];
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t blk_x0 = blockIdx.x * 32u;
@@ -188,13 +186,12 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV 
     PrimaryHit r;
     uint32_t dbg_listed = 0, dbg_tested = 0;  // RWR_FLAG_DEBUG_COUNTS (aux builds only)
     primary_visibility<CULL, AUX>(p, tris, ftris, s_prim, blk_x0, tile_x0, tile_y0, O, D, r, dbg_listed, dbg_tested);
-    if (!p.n_tris) __syncthreads();  // s_lut (the mesh loop's barriers cover it otherwise)
 
     // A pixel no pass wrote keeps the clear value (0,0,0,0); a written one gets
     // final_color with alpha 1 + 1 (compute.wgsl:231-234).
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
     if (r.obj != -1) {
-        const f3 c = shade_winner(p, r, tris, face_uv, tex, s_lut, O, D, nullptr);
+        const f3 c = shade_winner(p, r, tris, face_uv, tex, O, D, nullptr);
         cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
     }
 
@@ -212,17 +209,17 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV 
 }
 
 hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
-                          const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg)
+                          const FrameTri *ftris, const float4 *tex, const Targets &tg)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
     const dim3 grid((fp.width + 31u) / 32u, (fp.row_end - fp.row_begin + 7u) / 8u);
     const dim3 block(256);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
     const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
-    if (aux && do_cull) hipLaunchKernelGGL((k_primary<true, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
-    else if (aux) hipLaunchKernelGGL((k_primary<true, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
-    else if (do_cull) hipLaunchKernelGGL((k_primary<false, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
-    else hipLaunchKernelGGL((k_primary<false, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
+    if (aux && do_cull) hipLaunchKernelGGL((k_primary<true, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
+    else if (aux) hipLaunchKernelGGL((k_primary<true, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
+    else if (do_cull) hipLaunchKernelGGL((k_primary<false, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
+    else hipLaunchKernelGGL((k_primary<false, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
     return hipGetLastError();
 }
 

@@ -13,12 +13,10 @@ namespace rwr {
 template <bool AUX, bool CULL>
 __global__ void __launch_bounds__(256, 8)
 k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
-             const FrameTri *__restrict__ ftris, const uint32_t *__restrict__ tex, const float *__restrict__ srgb_lut,
+             const FrameTri *__restrict__ ftris, const float4 *__restrict__ tex,
              const Targets tg)
 {
-    __shared__ float s_lut[256];
     __shared__ PrimaryShared sh;
-    s_lut[threadIdx.x] = srgb_lut[threadIdx.x];
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t blk_x0 = blockIdx.x * 64u;
@@ -107,8 +105,6 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Face
             }
             if (base + 256u < n_src) __syncthreads();
         }
-    } else {
-        __syncthreads();  // s_lut
     }
     if (any2(best.have)) {
         const f2 current_depth = 1.0f - depth_tex;  // compute.wgsl:210
@@ -136,7 +132,7 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Face
         r.mesh.idx = k ? best.idx.y : best.idx.x;
         float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;  // untouched pixels keep the clear value
         if (r.obj != -1) {
-            const f3 c = shade_winner(p, r, tris, face_uv, tex, s_lut, O, lane3(D, k), nullptr);
+            const f3 c = shade_winner(p, r, tris, face_uv, tex, O, lane3(D, k), nullptr);
             cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
         }
         rgba[k] = pack_rgba8(cr, cg, cb, ca);
@@ -172,17 +168,17 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Face
 }
 
 hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
-                             const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg)
+                             const FrameTri *ftris, const float4 *tex, const Targets &tg)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
     const dim3 grid((fp.width + 63u) / 64u, (fp.row_end - fp.row_begin + 7u) / 8u);
     const dim3 block(256);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
     const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
-    if (aux && do_cull) hipLaunchKernelGGL((k_primary_p2<true, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
-    else if (aux) hipLaunchKernelGGL((k_primary_p2<true, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
-    else if (do_cull) hipLaunchKernelGGL((k_primary_p2<false, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
-    else hipLaunchKernelGGL((k_primary_p2<false, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg);
+    if (aux && do_cull) hipLaunchKernelGGL((k_primary_p2<true, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
+    else if (aux) hipLaunchKernelGGL((k_primary_p2<true, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
+    else if (do_cull) hipLaunchKernelGGL((k_primary_p2<false, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
+    else hipLaunchKernelGGL((k_primary_p2<false, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
     return hipGetLastError();
 }
 

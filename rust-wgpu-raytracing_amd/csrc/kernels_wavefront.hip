@@ -28,12 +28,10 @@ namespace rwr {
 template <bool AUX, bool CULL>
 __global__ void __launch_bounds__(256, 8)
 k_wf_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
-             const FrameTri *__restrict__ ftris, const uint32_t *__restrict__ tex, const float *__restrict__ srgb_lut,
+             const FrameTri *__restrict__ ftris, const float4 *__restrict__ tex,
              const Targets tg, const WfBuffers wf)
 {
-    __shared__ float s_lut[256];
     __shared__ PrimaryShared s_prim;
-    s_lut[threadIdx.x] = srgb_lut[threadIdx.x];
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t blk_x0 = blockIdx.x * 32u;
@@ -54,13 +52,12 @@ k_wf_primary(const FrameParams p, const TriRecord *__restrict__ tris, const Face
     PrimaryHit r;
     uint32_t dl = 0, dt = 0;
     primary_visibility<CULL, false>(p, tris, ftris, s_prim, blk_x0, tile_x0, tile_y0, O, D, r, dl, dt);
-    if (!p.n_tris) __syncthreads();  // s_lut
 
     const bool hit = r.obj != -1;
     float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     f3 albedo = mk3(0.0f, 0.0f, 0.0f);
     if (hit) {
-        const f3 c = shade_winner(p, r, tris, face_uv, tex, s_lut, O, D, &albedo);
+        const f3 c = shade_winner(p, r, tris, face_uv, tex, O, D, &albedo);
         e0 = make_float4(c.x, c.y, c.z, 2.0f);
     }
     if (in_range) {
@@ -122,23 +119,21 @@ k_wf_primary(const FrameParams p, const TriRecord *__restrict__ tris, const Face
 template <bool NODES_IN_LDS>
 __global__ void __launch_bounds__(256)
 k_wf_bounce(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
-            const BvhDevice bvh, const uint32_t *__restrict__ tex, const float *__restrict__ srgb_lut, const WfBuffers wf)
+            const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const uint32_t count = wf.seg_count[blockIdx.x];  // rays in this workgroup's queue segment
     if (count == 0u) return;                          // uniform
 
-    // LDS carve: [nodelets][stack][lut]
+    // LDS carve: [nodelets][stack]
     BvhNode4 *s_nodes = reinterpret_cast<BvhNode4 *>(s_dyn);
     const uint32_t node_bytes = NODES_IN_LDS ? bvh.n_nodes * (uint32_t)sizeof(BvhNode4) : 0u;
     uint32_t *s_stack = reinterpret_cast<uint32_t *>(s_dyn + node_bytes);
-    float *s_lut = reinterpret_cast<float *>(s_dyn + node_bytes + bvh.stack_depth * 256u * 4u);
     if (NODES_IN_LDS) {
         const float4 *src = reinterpret_cast<const float4 *>(bvh.nodes);
         float4 *dst = reinterpret_cast<float4 *>(s_nodes);
         for (uint32_t i = threadIdx.x; i < bvh.n_nodes * 8u; i += 256u) dst[i] = src[i];
     }
-    s_lut[threadIdx.x] = srgb_lut[threadIdx.x];
     __syncthreads();
 
     if (threadIdx.x >= count) return;  // no barrier below
@@ -170,7 +165,7 @@ k_wf_bounce(const FrameParams p, const TriRecord *__restrict__ tris, const FaceU
 
     PrimaryHit r;
     r.depth_tex = 0.0f; r.obj = obj; r.t = best_t; r.mesh = mh;
-    const f3 e1 = shade_winner(p, r, tris, face_uv, tex, s_lut, O, D, nullptr);
+    const f3 e1 = shade_winner(p, r, tris, face_uv, tex, O, D, nullptr);
     float4 acc = wf.accum[pixel];
     acc.x += thr.x * e1.x; acc.y += thr.y * e1.y; acc.z += thr.z * e1.z;
     wf.accum[pixel] = acc;
@@ -192,32 +187,32 @@ k_wf_resolve(const FrameParams p, const Targets tg, const WfBuffers wf)
 }
 
 hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
-                             const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg,
+                             const FrameTri *ftris, const float4 *tex, const Targets &tg,
                              const WfBuffers &wf)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
     const dim3 grid((fp.width + 31u) / 32u, (fp.row_end - fp.row_begin + 7u) / 8u);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0, do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
-    if (aux && do_cull) hipLaunchKernelGGL((k_wf_primary<true, true>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg, wf);
-    else if (aux) hipLaunchKernelGGL((k_wf_primary<true, false>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg, wf);
-    else if (do_cull) hipLaunchKernelGGL((k_wf_primary<false, true>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg, wf);
-    else hipLaunchKernelGGL((k_wf_primary<false, false>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, srgb_lut, tg, wf);
+    if (aux && do_cull) hipLaunchKernelGGL((k_wf_primary<true, true>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, tg, wf);
+    else if (aux) hipLaunchKernelGGL((k_wf_primary<true, false>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, tg, wf);
+    else if (do_cull) hipLaunchKernelGGL((k_wf_primary<false, true>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, tg, wf);
+    else hipLaunchKernelGGL((k_wf_primary<false, false>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, tg, wf);
     return hipGetLastError();
 }
 
 hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
-                            const BvhDevice &bvh, const uint32_t *tex, const float *srgb_lut, const WfBuffers &wf,
+                            const BvhDevice &bvh, const float4 *tex, const WfBuffers &wf,
                             uint32_t n_segments)
 {
     if (n_segments == 0) return hipSuccess;
     const dim3 grid(n_segments);
-    const size_t fixed = (size_t)bvh.stack_depth * 256u * 4u + 256u * 4u;
+    const size_t fixed = (size_t)bvh.stack_depth * 256u * 4u;
     const size_t node_bytes = (size_t)bvh.n_nodes * sizeof(BvhNode4);
     // nodelets go to LDS when they leave room for >= 2 workgroups per CU (160 KiB LDS)
     if (node_bytes + fixed <= 64u * 1024u) {
-        hipLaunchKernelGGL((k_wf_bounce<true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, face_uv, bvh, tex, srgb_lut, wf);
+        hipLaunchKernelGGL((k_wf_bounce<true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, face_uv, bvh, tex, wf);
     } else {
-        hipLaunchKernelGGL((k_wf_bounce<false>), grid, dim3(256), fixed, s, fp, tris, face_uv, bvh, tex, srgb_lut, wf);
+        hipLaunchKernelGGL((k_wf_bounce<false>), grid, dim3(256), fixed, s, fp, tris, face_uv, bvh, tex, wf);
     }
     return hipGetLastError();
 }

@@ -131,9 +131,10 @@ RWR_DEV f3 shade_sphere(f3 n, f3 D)
 
 // Rgba8UnormSrgb texel fetch + bilinear filter with ClampToEdge
 // (texture.rs:122,151-159; textureSampleGrad at LOD 0, compute.wgsl:225).
-// `lut` is the 256-entry sRGB->linear table in LDS.
-RWR_DEV f3 tex_sample_bilinear(const uint32_t *__restrict__ tex, uint32_t tw, uint32_t th, const float *lut,
-                               float u, float v)
+// `tex` holds the texels already decoded to linear f32 (one float4 per texel, made at
+// upload from the same 256-entry sRGB table the oracle uses): what the sampler
+// hardware does before filtering, done once instead of per tap.
+RWR_DEV f3 tex_sample_bilinear(const float4 *__restrict__ tex, uint32_t tw, uint32_t th, float u, float v)
 {
     float fx = u * (float)tw - 0.5f;
     float fy = v * (float)th - 0.5f;
@@ -144,16 +145,13 @@ RWR_DEV f3 tex_sample_bilinear(const uint32_t *__restrict__ tex, uint32_t tw, ui
     uint32_t x1 = (uint32_t)fminf(fmaxf(x0f + 1.0f, 0.0f), wmax);
     uint32_t y0 = (uint32_t)fminf(fmaxf(y0f, 0.0f), hmax);
     uint32_t y1 = (uint32_t)fminf(fmaxf(y0f + 1.0f, 0.0f), hmax);
-    uint32_t t00 = tex[y0 * tw + x0], t10 = tex[y0 * tw + x1];
-    uint32_t t01 = tex[y1 * tw + x0], t11 = tex[y1 * tw + x1];
+    const float4 t00 = tex[y0 * tw + x0], t10 = tex[y0 * tw + x1];
+    const float4 t01 = tex[y1 * tw + x0], t11 = tex[y1 * tw + x1];
     float w00 = (1.0f - ax) * (1.0f - ay), w10 = ax * (1.0f - ay);
     float w01 = (1.0f - ax) * ay, w11 = ax * ay;
-    auto mix = [&](uint32_t sh) {
-        return __builtin_fmaf(lut[(t11 >> sh) & 255u], w11,
-               __builtin_fmaf(lut[(t01 >> sh) & 255u], w01,
-               __builtin_fmaf(lut[(t10 >> sh) & 255u], w10, lut[(t00 >> sh) & 255u] * w00)));
-    };
-    return mk3(mix(0u), mix(8u), mix(16u));
+    return mk3(__builtin_fmaf(t11.x, w11, __builtin_fmaf(t01.x, w01, __builtin_fmaf(t10.x, w10, t00.x * w00))),
+               __builtin_fmaf(t11.y, w11, __builtin_fmaf(t01.y, w01, __builtin_fmaf(t10.y, w10, t00.y * w00))),
+               __builtin_fmaf(t11.z, w11, __builtin_fmaf(t01.z, w01, __builtin_fmaf(t10.z, w10, t00.z * w00))));
 }
 
 // Mesh shading, triangle_list/compute.wgsl:217-234 (colour path: see the header).
@@ -161,8 +159,7 @@ RWR_DEV f3 tex_sample_bilinear(const uint32_t *__restrict__ tex, uint32_t tw, ui
 // N_facing the face normal already flipped towards the ray (compute.wgsl:140-147).
 // *albedo receives the filtered texel.
 RWR_DEV f3 shade_mesh(const FaceUV &fuv, float eu, float ev, float denom, f3 N_facing, f3 D, const float *ka,
-                      const float *ks, const uint32_t *__restrict__ tex, uint32_t tw, uint32_t th, const float *lut,
-                      f3 *albedo)
+                      const float *ks, const float4 *__restrict__ tex, uint32_t tw, uint32_t th, f3 *albedo)
 {
     const float rden = __builtin_amdgcn_rcpf(denom);
     const float b0 = eu * rden, b1 = ev * rden, b2 = 1.0f - b0 - b1;   // barycentric (u, v, 1-u-v), :144-147
@@ -170,7 +167,7 @@ RWR_DEV f3 shade_mesh(const FaceUV &fuv, float eu, float ev, float denom, f3 N_f
     float tu = __builtin_fmaf(b2, fuv.uv2[0], __builtin_fmaf(b1, fuv.uv1[0], b0 * fuv.uv0[0]));
     float tv = __builtin_fmaf(b2, fuv.uv2[1], __builtin_fmaf(b1, fuv.uv1[1], b0 * fuv.uv0[1]));
     tv = 1.0f - tv;
-    f3 texel = tex_sample_bilinear(tex, tw, th, lut, tu, tv);
+    f3 texel = tex_sample_bilinear(tex, tw, th, tu, tv);
     if (albedo) *albedo = texel;
     const f3 nl = neg3(normalize3(mk3(1.0f, -1.0f, -5.0f)));  // -normalize(kLightDir), :55 (folded at compile time)
     float ndl = fmaxf(0.0f, cdot(n, nl));

@@ -146,12 +146,12 @@ struct BvhDevice {
 };
 
 hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
-                             const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg);
+                             const FrameTri *ftris, const float4 *tex, const Targets &tg);
 hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
-                             const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg,
+                             const FrameTri *ftris, const float4 *tex, const Targets &tg,
                              const WfBuffers &wf);
 hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
-                            const BvhDevice &bvh, const uint32_t *tex, const float *srgb_lut, const WfBuffers &wf,
+                            const BvhDevice &bvh, const float4 *tex, const WfBuffers &wf,
                             uint32_t n_segments);
 hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf);
 
@@ -159,6 +159,6 @@ hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const CullRec
 hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *lists,
                             uint32_t *counts, uint32_t bins_x, uint32_t bins_y, uint32_t cap);
 hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
-                          const FrameTri *ftris, const uint32_t *tex, const float *srgb_lut, const Targets &tg);
+                          const FrameTri *ftris, const float4 *tex, const Targets &tg);
 
 }  // namespace rwr

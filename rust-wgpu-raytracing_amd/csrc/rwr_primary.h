@@ -128,15 +128,14 @@ RWR_DEV void primary_visibility(const FrameParams &p, const TriRecord *__restric
 // Local shading E of the winning surface (colour path) -> rgb; alpha is 2.0 on a hit.
 // *albedo (may be null) receives the surface's diffuse reflectance.
 RWR_DEV f3 shade_winner(const FrameParams &p, const PrimaryHit &r, const TriRecord *__restrict__ tris,
-                        const FaceUV *__restrict__ face_uv, const uint32_t *__restrict__ tex, const float *lut, f3 O,
-                        f3 D, f3 *albedo)
+                        const FaceUV *__restrict__ face_uv, const float4 *__restrict__ tex, f3 O, f3 D, f3 *albedo)
 {
     if (r.obj >= 0) {
         const TriRecord &T = tris[r.obj];
         f3 N = ld3(T.N);
         if (r.mesh.ndotd > 0.0f) N = neg3(N);  // compute.wgsl:140-142
         return shade_mesh(face_uv[r.obj], r.mesh.u, r.mesh.v, T.denom, N, D, p.ambient, p.specular, tex, p.tex_w, p.tex_h,
-                          lut, albedo);
+                          albedo);
     }
     const uint32_t k = (uint32_t)(-2 - r.obj);
     const f3 P = along(O, r.t, D);
