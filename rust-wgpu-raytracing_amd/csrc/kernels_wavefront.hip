@@ -209,6 +209,10 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
     const size_t fixed = (size_t)bvh.stack_depth * 256u * 4u;
     const size_t node_bytes = (size_t)bvh.n_nodes * sizeof(BvhNode4);
     // nodelets go to LDS when they leave room for >= 2 workgroups per CU (160 KiB LDS)
+    // nodelets go to LDS when they leave room for >= 2 workgroups per CU (160 KiB LDS).
+    // (A persistent one-wave-per-segment form with dynamic ray hand-out was built and measured
+    // 35 % SLOWER — 26.2 vs 19.7 ms at cfg3: a quarter of the waves, so less latency hiding and a
+    // longer tail, for no gain in lane utilisation once finished rays are retired in groups.)
     if (node_bytes + fixed <= 64u * 1024u) {
         hipLaunchKernelGGL((k_wf_bounce<true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, face_uv, bvh, tex, wf);
     } else {

@@ -56,77 +56,100 @@ RWR_DEV void intersect_and_select_any_order(const TriRecord &T, uint32_t idx, f3
     }
 }
 
-// nodes: LDS (or global) array of BvhNode4, root at 0.
-// stack: LDS, (3 * tree depth + 2) * blockDim.x words (the host sizes it: a 4-wide
-// node pushes at most 3 entries beyond the one it pops, so it cannot overflow).
-// "while-while" shape: every lane first walks inner nodes until it holds a leaf (or
-// runs dry), then the wave tests leaves together — inner-node and leaf work are not
-// serialised against each other inside one iteration.
-//
-// The kernel is VALU-bound and most of a node visit is bookkeeping, so that is kept
-// lean: "behind the origin" and "farther than the best hit" fold into the interval test
-// max(tnear, 0) <= min(tfar, best_t); the nearest surviving child is found as the
-// unsigned minimum of keys (entry distance bits with the slot in the low 2 bits) — no
-// sorting network; the other survivors are pushed unordered.
+// Ray constants of the slab test:  t = b * inv - O * inv  (one FMA per plane; conservative
+// code may fuse).  +-inf for axis-parallel rays is fine, see bvh_inner_step.
+struct SlabRay { float ix, iy, iz, ox, oy, oz; };
+RWR_DEV SlabRay make_slab_ray(f3 O, f3 D)
+{
+    SlabRay r;
+    r.ix = 1.0f / D.x; r.iy = 1.0f / D.y; r.iz = 1.0f / D.z;
+    r.ox = -O.x * r.ix; r.oy = -O.y * r.iy; r.oz = -O.z * r.iz;
+    return r;
+}
+
+// One inner-node visit of one lane: tests the four child boxes, continues with the nearest
+// survivor (returned in `cur`) and pushes the others; pops when nothing survives.  Returns
+// false when the lane's traversal is finished (stack empty).
+// The kernel is VALU-bound and most of a node visit is bookkeeping, so that is kept lean:
+// "behind the origin" and "farther than the best hit" fold into the interval test
+// max(tnear, 0) <= min(tfar, best_t); the nearest surviving child is found as the unsigned
+// minimum of keys (entry distance bits with the slot in the low 2 bits) — no sorting network;
+// the other survivors are pushed unordered.  (An empty slot's inverted box does NOT fail a
+// min/max slab test by itself: the link is tested.)
+template <typename NodePtr>
+RWR_DEV bool bvh_inner_step(NodePtr nodes, const SlabRay &sr, float tbest, uint32_t &cur, uint32_t *&sp, uint32_t *sp0,
+                            uint32_t stride)
+{
+    uint32_t key[4], child[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        child[i] = nodes[cur].child[i];
+        // NaN (0 * inf: origin exactly on a slab plane of an axis-parallel ray) is ignored by min/max
+        const float x0 = __builtin_fmaf(nodes[cur].bmin_x[i], sr.ix, sr.ox), x1 = __builtin_fmaf(nodes[cur].bmax_x[i], sr.ix, sr.ox);
+        const float y0 = __builtin_fmaf(nodes[cur].bmin_y[i], sr.iy, sr.oy), y1 = __builtin_fmaf(nodes[cur].bmax_y[i], sr.iy, sr.oy);
+        const float z0 = __builtin_fmaf(nodes[cur].bmin_z[i], sr.iz, sr.oz), z1 = __builtin_fmaf(nodes[cur].bmax_z[i], sr.iz, sr.oz);
+        const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        // conservative: relative slack on both distances; equal-distance nodes are kept (<=)
+        const float lo = fmaxf(tnear - 4e-5f * fabsf(tnear), 0.0f);
+        const float hi = fminf(tfar + 4e-5f * fabsf(tfar) + 1e-30f, tbest);
+        // lo >= 0, so its bit pattern orders like the float; low 2 bits carry the slot
+        key[i] = (lo <= hi && child[i] != kBvhEmpty) ? ((__float_as_uint(lo) & ~3u) | (uint32_t)i) : 0xffffffffu;
+    }
+    const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+    if (kmin == 0xffffffffu) {  // nothing survived: pop
+        if (sp == sp0) return false;
+        sp -= stride;
+        cur = *sp;
+        return true;
+    }
+    const uint32_t near_slot = kmin & 3u;
+    uint32_t next = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if ((uint32_t)i == near_slot) next = child[i];
+        else if (key[i] != 0xffffffffu) { *sp = child[i]; sp += stride; }
+    }
+    cur = next;
+    return true;
+}
+
+// One leaf visit of one lane: exact tests of the leaf's faces, then pop.  Returns false when
+// the lane's traversal is finished.
+RWR_DEV bool bvh_leaf_step(const uint32_t *__restrict__ leaf_faces, const TriRecord *__restrict__ tris, uint32_t n_faces,
+                           f3 O, f3 D, MeshHit &best, uint32_t &cur, uint32_t *&sp, uint32_t *sp0, uint32_t stride)
+{
+    const uint32_t first = (cur & ~kBvhLeafBit) >> 3, count = (cur & 7u) + 1u;
+    for (uint32_t k = 0; k < count; k++) {
+        if (first + k >= n_faces) break;  // cannot happen with a well-formed tree; keeps a bad link from faulting
+        const uint32_t idx = leaf_faces[first + k];
+        if (idx < n_faces) intersect_and_select_any_order(tris[idx], idx, O, D, best);
+    }
+    if (sp == sp0) return false;
+    sp -= stride;
+    cur = *sp;
+    return true;
+}
+
+// Nearest hit of one ray per lane.  nodes: LDS (or global) array of BvhNode4, root at 0.
+// stack: LDS, (3 * tree depth + 2) * stride words, this lane's column at stack + lane
+// (the host sizes it: a 4-wide node pushes at most 3 entries beyond the one it pops).
+// "while-while" shape: every lane first walks inner nodes until it holds a leaf (or runs
+// dry), then the wave tests leaves together.
 template <typename NodePtr>
 RWR_DEV void bvh_nearest(NodePtr nodes, const uint32_t *__restrict__ leaf_faces, const TriRecord *__restrict__ tris,
                          uint32_t n_faces, uint32_t *stack, f3 O, f3 D, MeshHit &best)
 {
-    // slab planes through  t = b * inv - O * inv  (one FMA each; conservative code may fuse)
-    const float ix = 1.0f / D.x, iy = 1.0f / D.y, iz = 1.0f / D.z;  // +-inf for axis-parallel rays is fine below
-    const float ox = -O.x * ix, oy = -O.y * iy, oz = -O.z * iz;
+    const SlabRay sr = make_slab_ray(O, D);
     const uint32_t stride = blockDim.x;
-    uint32_t *sp = stack + threadIdx.x;       // next free slot of this lane's stack
+    uint32_t *sp = stack + threadIdx.x;  // next free slot of this lane's stack
     uint32_t *const sp0 = sp;
     uint32_t cur = 0;  // the root is always an inner node
     bool have_cur = true;
     while (__any(have_cur)) {
-        // phase 1: inner nodes
-        while (have_cur && !(cur & kBvhLeafBit)) {
-            const float tbest = best.have ? best.t : __builtin_inff();
-            uint32_t key[4], child[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                child[i] = nodes[cur].child[i];
-                // NaN (0 * inf: origin exactly on a slab plane of an axis-parallel ray) is ignored by min/max
-                const float x0 = __builtin_fmaf(nodes[cur].bmin_x[i], ix, ox), x1 = __builtin_fmaf(nodes[cur].bmax_x[i], ix, ox);
-                const float y0 = __builtin_fmaf(nodes[cur].bmin_y[i], iy, oy), y1 = __builtin_fmaf(nodes[cur].bmax_y[i], iy, oy);
-                const float z0 = __builtin_fmaf(nodes[cur].bmin_z[i], iz, oz), z1 = __builtin_fmaf(nodes[cur].bmax_z[i], iz, oz);
-                const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                // conservative: relative slack on both distances; equal-distance nodes are kept (<=)
-                const float lo = fmaxf(tnear - 4e-5f * fabsf(tnear), 0.0f);
-                const float hi = fminf(tfar + 4e-5f * fabsf(tfar) + 1e-30f, tbest);
-                // lo >= 0, so its bit pattern orders like the float; low 2 bits carry the slot
-                // (an empty slot's inverted box does NOT fail a min/max slab test by itself: test the link)
-                key[i] = (lo <= hi && child[i] != kBvhEmpty) ? ((__float_as_uint(lo) & ~3u) | (uint32_t)i) : 0xffffffffu;
-            }
-            const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
-            if (kmin == 0xffffffffu) {  // nothing survived: pop
-                have_cur = sp != sp0;
-                if (have_cur) { sp -= stride; cur = *sp; }
-            } else {
-                const uint32_t near_slot = kmin & 3u;
-                uint32_t next = 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if ((uint32_t)i == near_slot) next = child[i];
-                    else if (key[i] != 0xffffffffu) { *sp = child[i]; sp += stride; }
-                }
-                cur = next;
-            }
-        }
-        // phase 2: the leaf this lane arrived at
-        if (have_cur) {
-            const uint32_t first = (cur & ~kBvhLeafBit) >> 3, count = (cur & 7u) + 1u;
-            for (uint32_t k = 0; k < count; k++) {
-                if (first + k >= n_faces) break;  // cannot happen with a well-formed tree; keeps a bad link from faulting
-                const uint32_t idx = leaf_faces[first + k];
-                if (idx < n_faces) intersect_and_select_any_order(tris[idx], idx, O, D, best);
-            }
-            have_cur = sp != sp0;
-            if (have_cur) { sp -= stride; cur = *sp; }
-        }
+        while (have_cur && !(cur & kBvhLeafBit))
+            have_cur = bvh_inner_step(nodes, sr, best.have ? best.t : __builtin_inff(), cur, sp, sp0, stride);
+        if (have_cur) have_cur = bvh_leaf_step(leaf_faces, tris, n_faces, O, D, best, cur, sp, sp0, stride);
     }
 }
 
