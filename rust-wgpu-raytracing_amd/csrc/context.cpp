@@ -533,9 +533,11 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         // previous frame, was measured 4-10 us SLOWER per frame than the 3 us it hides:
         // cross-stream event waits cost more than the kernel.)
         RWR_HIP_CHECK(launch_frame_setup(ctx->stream, cc, ctx->d_cull.ptr, ctx->n_tris, ctx->d_ftris.ptr));
-        if (ctx->n_tris > ctx->bin_min_faces) {
+        const uint32_t bins_x = (ctx->screen.width + kBinW - 1) / kBinW, bins_y = (row_end - row_begin + kBinH - 1) / kBinH;
+        // bin lists are worst-case sized (every face in every bin); beyond 2 GiB fall back to the un-binned walk
+        const bool bins_fit = (uint64_t)bins_x * bins_y * ctx->n_tris * sizeof(uint32_t) <= (2ull << 30);
+        if (ctx->n_tris > ctx->bin_min_faces && bins_fit) {
             // more faces than one 256-wide batch: bin them per 64x32-pixel screen region, once per frame
-            const uint32_t bins_x = (ctx->screen.width + kBinW - 1) / kBinW, bins_y = (row_end - row_begin + kBinH - 1) / kBinH;
             RWR_HIP_CHECK(ctx->d_bin_lists.ensure((size_t)bins_x * bins_y * ctx->n_tris));
             RWR_HIP_CHECK(ctx->d_bin_counts.ensure((size_t)bins_x * bins_y));
             RWR_HIP_CHECK(launch_bin_faces(ctx->stream, ctx->d_ftris.ptr, ctx->n_tris, row_begin, ctx->d_bin_lists.ptr,
@@ -552,13 +554,17 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
             ctx->timing_events.push_back(a);
             ctx->timing_events.push_back(b);
         }
-        RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs], ctx->stream));
     }
+    // the two-pixel frame kernel is timed by its own dispatch timestamps; everything else by stream events
+    const bool dispatch_timed = time_this && !wavefront && !((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel);
+    if (time_this && !dispatch_timed) RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs], ctx->stream));
     if (!wavefront) {
         if ((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel)
             RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, tg));
         else
-            RWR_HIP_CHECK(launch_primary_p2(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, tg));
+            RWR_HIP_CHECK(launch_primary_p2(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, tg,
+                                            dispatch_timed ? ctx->timing_events[2 * ctx->timing_pairs] : nullptr,
+                                            dispatch_timed ? ctx->timing_events[2 * ctx->timing_pairs + 1] : nullptr));
         ctx->last_spp = 0;
     } else {
         // wavefront integrator: per sample pass, primary stage then (queue-driven) bounce stage
@@ -588,7 +594,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         ctx->last_had_bounce = rp.max_bounces != 0;
     }
     if (time_this) {
-        RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs + 1], ctx->stream));
+        if (!dispatch_timed) RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs + 1], ctx->stream));
         ctx->timing_pairs++;
     }
     ctx->aux_valid = aux;

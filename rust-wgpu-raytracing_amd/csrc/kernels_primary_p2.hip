@@ -5,6 +5,8 @@
 //   wave64  = 16x8 pixel tile, lane l owns pixels (2*(l&7), l>>3) and (2*(l&7)+1, l>>3);
 //   workgroup (4 waves) = 64x8 pixels = one screen-bin column (kBinW), so a row of the
 //   RGBA8 / R32F targets is written as 256 contiguous bytes by one workgroup, 8 B per lane.
+#include <hip/hip_ext.h>
+
 #include "rwr_device_p2.h"
 #include "rwr_primary.h"
 
@@ -168,17 +170,20 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Face
 }
 
 hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
-                             const FrameTri *ftris, const float4 *tex, const Targets &tg)
+                             const FrameTri *ftris, const float4 *tex, const Targets &tg, hipEvent_t ev_start,
+                             hipEvent_t ev_stop)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
     const dim3 grid((fp.width + 63u) / 64u, (fp.row_end - fp.row_begin + 7u) / 8u);
     const dim3 block(256);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
     const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
-    if (aux && do_cull) hipLaunchKernelGGL((k_primary_p2<true, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
-    else if (aux) hipLaunchKernelGGL((k_primary_p2<true, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
-    else if (do_cull) hipLaunchKernelGGL((k_primary_p2<false, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
-    else hipLaunchKernelGGL((k_primary_p2<false, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
+    // ev_start / ev_stop (may be null): timestamps of this dispatch itself (hipExtLaunchKernelGGL), i.e. the
+    // kernel's own duration as a profiler reports it, without the gap to the preceding kernel
+    if (aux && do_cull) hipExtLaunchKernelGGL((k_primary_p2<true, true>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, face_uv, ftris, tex, tg);
+    else if (aux) hipExtLaunchKernelGGL((k_primary_p2<true, false>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, face_uv, ftris, tex, tg);
+    else if (do_cull) hipExtLaunchKernelGGL((k_primary_p2<false, true>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, face_uv, ftris, tex, tg);
+    else hipExtLaunchKernelGGL((k_primary_p2<false, false>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, face_uv, ftris, tex, tg);
     return hipGetLastError();
 }
 

@@ -146,7 +146,8 @@ struct BvhDevice {
 };
 
 hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
-                             const FrameTri *ftris, const float4 *tex, const Targets &tg);
+                             const FrameTri *ftris, const float4 *tex, const Targets &tg, hipEvent_t ev_start = nullptr,
+                             hipEvent_t ev_stop = nullptr);
 hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
                              const FrameTri *ftris, const float4 *tex, const Targets &tg,
                              const WfBuffers &wf);
