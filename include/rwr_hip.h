@@ -120,7 +120,9 @@ typedef struct rwr_render_params {
 enum {
     RWR_FLAG_AUX_OUTPUTS = 1u << 0, /* also produce float colour, object id and hit distance planes */
     RWR_FLAG_NO_CULL     = 1u << 1, /* debug: brute-force every face for every pixel (reference loop order) */
-    RWR_FLAG_USE_BVH     = 1u << 2  /* primary rays traverse the BVH instead of tile-frustum culling */
+    RWR_FLAG_USE_BVH     = 1u << 2  /* reference frame only: the mesh pass traverses the BVH per ray instead of
+                                       walking per-tile candidate lists (better when many small faces share a
+                                       tile, e.g. a distant mesh); same result bit for bit */
 };
 
 #define RWR_MAX_SPHERES 8

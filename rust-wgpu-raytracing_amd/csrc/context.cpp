@@ -486,7 +486,8 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     if (params) rp = *params;
     if (rp.spp == 0) return set_error(RWR_ERR_INVALID_ARGUMENT, "spp must be >= 1");
     if (rp.max_bounces > 1) return set_error(RWR_ERR_UNSUPPORTED, "max_bounces > 1 is not supported");
-    if (rp.flags & RWR_FLAG_USE_BVH) return set_error(RWR_ERR_UNSUPPORTED, "RWR_FLAG_USE_BVH for primary rays is not implemented");
+    if ((rp.flags & RWR_FLAG_USE_BVH) && (rp.spp != 1 || rp.max_bounces != 0))
+        return set_error(RWR_ERR_UNSUPPORTED, "RWR_FLAG_USE_BVH applies to the reference frame (spp 1, no bounce); bounce rays always use the BVH");
     if (rp.spp > 4096) return set_error(RWR_ERR_INVALID_ARGUMENT, "spp must be <= 4096");
     const bool wavefront = rp.spp != 1 || rp.max_bounces != 0;
 
@@ -556,9 +557,14 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         }
     }
     // the two-pixel frame kernel is timed by its own dispatch timestamps; everything else by stream events
-    const bool dispatch_timed = time_this && !wavefront && !((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel);
+    const bool dispatch_timed = time_this && !wavefront && !(rp.flags & RWR_FLAG_USE_BVH) &&
+                                !((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel);
     if (time_this && !dispatch_timed) RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs], ctx->stream));
-    if (!wavefront) {
+    if (!wavefront && (rp.flags & RWR_FLAG_USE_BVH)) {
+        const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
+        RWR_HIP_CHECK(launch_primary_bvh(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, bvh_p, ctx->d_tex.ptr, tg));
+        ctx->last_spp = 0;
+    } else if (!wavefront) {
         if ((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel)
             RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, tg));
         else

@@ -171,6 +171,90 @@ k_wf_bounce(const FrameParams p, const TriRecord *__restrict__ tris, const FaceU
     wf.accum[pixel] = acc;
 }
 
+// RWR_FLAG_USE_BVH: the reference frame with the mesh pass done by per-lane BVH traversal
+// instead of candidate lists — for views where many small faces fall into one tile (a distant
+// or finely tessellated mesh), where a wave would otherwise walk every face of its block.
+// Same spheres, same exact hit test, ties by face index: results are bit-identical to k_primary.
+// A separate kernel on purpose: inlined into (or called from) k_primary the traversal's register
+// needs slowed EVERY frame 2.5x.
+template <bool AUX, bool NODES_IN_LDS>
+__global__ void __launch_bounds__(256)
+k_primary_bvh(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
+              const BvhDevice bvh, const float4 *__restrict__ tex, const Targets tg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    BvhNode4 *s_nodes = reinterpret_cast<BvhNode4 *>(s_dyn);
+    const uint32_t node_bytes = NODES_IN_LDS ? bvh.n_nodes * (uint32_t)sizeof(BvhNode4) : 0u;
+    uint32_t *s_stack = reinterpret_cast<uint32_t *>(s_dyn + node_bytes);
+    if (NODES_IN_LDS) {
+        const float4 *src = reinterpret_cast<const float4 *>(bvh.nodes);
+        float4 *dst = reinterpret_cast<float4 *>(s_nodes);
+        for (uint32_t i = threadIdx.x; i < bvh.n_nodes * 8u; i += 256u) dst[i] = src[i];
+        __syncthreads();
+    }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t px = blockIdx.x * 32u + wave * 8u + (lane & 7u), py = p.row_begin + blockIdx.y * 8u + (lane >> 3);
+    const bool in_range = (px < p.width) && (py < p.row_end);
+    const f3 O = ld3(p.cam.origin);
+    const f3 D = pixel_to_ray_dir(p.cam, px, py, 0.5f, 0.5f, p.width, p.height);
+
+    PrimaryHit r;
+    r.depth_tex = 0.0f; r.obj = -1; r.t = 0.0f;
+    for (uint32_t s = 0; s < p.n_spheres; s++) {  // sphere passes in order (lib.rs:1106-1173)
+        float t;
+        if (sphere_ray_intersect_t(ld3(p.spheres[s].center), p.spheres[s].radius, O, D, t)) {
+            const float current_depth = 1.0f - r.depth_tex;
+            const float depth = to_non_linear_depth(t);
+            if (!(depth >= current_depth)) { r.depth_tex = 1.0f - depth; r.obj = -2 - (int32_t)s; r.t = t; }
+        }
+    }
+    MeshHit best;
+    best.have = false; best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.ndotd = 0.0f; best.idx = 0u;
+    if (p.n_tris) {
+        if (NODES_IN_LDS) bvh_nearest(s_nodes, bvh.leaf_faces, tris, p.n_tris, s_stack, O, D, best);
+        else bvh_nearest(bvh.nodes, bvh.leaf_faces, tris, p.n_tris, s_stack, O, D, best);
+    }
+    r.mesh = best;
+    if (best.have) {  // mesh pass depth test (compute.wgsl:210-215)
+        const float current_depth = 1.0f - r.depth_tex;
+        const float depth = to_non_linear_depth(best.t);
+        if (!(depth >= current_depth)) { r.depth_tex = 1.0f - depth; r.obj = (int32_t)best.idx; r.t = best.t; }
+    }
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
+    if (r.obj != -1) {
+        const f3 c = shade_winner(p, r, tris, face_uv, tex, O, D, nullptr);
+        cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
+    }
+    if (in_range) {
+        const size_t o = (size_t)py * p.width + px;
+        reinterpret_cast<uint32_t *>(tg.color)[o] = pack_rgba8(cr, cg, cb, ca);
+        tg.depth[o] = r.depth_tex;
+        if (AUX) {
+            reinterpret_cast<float4 *>(tg.color_f32)[o] = make_float4(cr, cg, cb, ca);
+            tg.obj_id[o] = r.obj;
+            tg.hit_t[o] = r.t;
+        }
+    }
+}
+
+hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+                              const BvhDevice &bvh, const float4 *tex, const Targets &tg)
+{
+    if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
+    const dim3 grid((fp.width + 31u) / 32u, (fp.row_end - fp.row_begin + 7u) / 8u);
+    const size_t fixed = (size_t)bvh.stack_depth * 256u * 4u;
+    const size_t node_bytes = (size_t)bvh.n_nodes * sizeof(BvhNode4);
+    const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
+    if (node_bytes + fixed <= 64u * 1024u) {
+        if (aux) hipLaunchKernelGGL((k_primary_bvh<true, true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, face_uv, bvh, tex, tg);
+        else hipLaunchKernelGGL((k_primary_bvh<false, true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, face_uv, bvh, tex, tg);
+    } else {
+        if (aux) hipLaunchKernelGGL((k_primary_bvh<true, false>), grid, dim3(256), fixed, s, fp, tris, face_uv, bvh, tex, tg);
+        else hipLaunchKernelGGL((k_primary_bvh<false, false>), grid, dim3(256), fixed, s, fp, tris, face_uv, bvh, tex, tg);
+    }
+    return hipGetLastError();
+}
+
 template <bool AUX>
 __global__ void __launch_bounds__(256)
 k_wf_resolve(const FrameParams p, const Targets tg, const WfBuffers wf)

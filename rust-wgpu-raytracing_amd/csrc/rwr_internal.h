@@ -154,6 +154,8 @@ hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriReco
 hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
                             const BvhDevice &bvh, const float4 *tex, const WfBuffers &wf,
                             uint32_t n_segments);
+hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+                              const BvhDevice &bvh, const float4 *tex, const Targets &tg);
 hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf);
 
 hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const CullRec *cull, uint32_t n_tris, FrameTri *ftris);

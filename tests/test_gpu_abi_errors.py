@@ -34,7 +34,8 @@ def test_render_before_setup_and_bad_arguments(rwr, suzanne):
         with pytest.raises(rwr.RwrError) as ei:
             ctx.render(cam_inv, rows=(10, 200))
         assert ei.value.code == rwr.ERR_INVALID_ARGUMENT
-        for params, code in ((rwr.make_params(spp=0), rwr.ERR_INVALID_ARGUMENT), (rwr.make_params(max_bounces=2), rwr.ERR_UNSUPPORTED)):
+        for params, code in ((rwr.make_params(spp=0), rwr.ERR_INVALID_ARGUMENT), (rwr.make_params(max_bounces=2), rwr.ERR_UNSUPPORTED),
+                             (rwr.make_params(spp=2, flags=rwr.FLAG_USE_BVH), rwr.ERR_UNSUPPORTED)):
             with pytest.raises(rwr.RwrError) as ei:
                 ctx.render(cam_inv, params)
             assert ei.value.code == code

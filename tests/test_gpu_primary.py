@@ -152,3 +152,15 @@ def test_two_pixel_and_one_pixel_kernels_agree(rwr, gpu_ctx, suzanne, cube):
         b = _render_gpu(rwr, gpu_ctx, model, rwr.make_spheres(), cam_inv, w, h, flags=rwr.FLAG_ONE_PIXEL_PER_LANE)
         for k in a:
             assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), (w, h, k)
+
+
+def test_bvh_frame_kernel_agrees(rwr, gpu_ctx, suzanne, cube):
+    """RWR_FLAG_USE_BVH (per-ray BVH traversal for the mesh pass) is bit-identical to the
+    candidate-list kernel: same exact test, ties by face index."""
+    for model, cam_kw, (w, h) in [(suzanne, CAMERAS["reference_default_inside_mesh"], (200, 113)), (suzanne, CAMERAS["far_away"], (96, 54)),
+                                  (suzanne, CAMERAS["spheres_visible"], (77, 64)), (cube, dict(eye=(2.2, 1.7, 3.1), target=(0, 0, 0)), (128, 96))]:
+        cam_inv = rwr.camera_build_inv_uniform(rwr.make_camera(aspect=w / h, **cam_kw))
+        a = _render_gpu(rwr, gpu_ctx, model, rwr.make_spheres(), cam_inv, w, h)
+        b = _render_gpu(rwr, gpu_ctx, model, rwr.make_spheres(), cam_inv, w, h, flags=rwr.FLAG_USE_BVH)
+        for k in a:
+            assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), (w, h, k)

@@ -28,4 +28,6 @@ for (w, h) in [(1920, 1080), (256, 256)]:
     run("suzanne, eye (0,0,40) (all misses)", suz, S, (0, 0, 40), w, h)
     run("suzanne, eye 0, NO_CULL", suz, S, (0, 0, 0), w, h, r.FLAG_NO_CULL)
     run("cube, eye 0", cube, S, (0, 0, 0), w, h)
+    run("suzanne, eye 0, USE_BVH", suz, S, (0, 0, 0), w, h, r.FLAG_USE_BVH)
+    run("suzanne, eye (0,0,40), USE_BVH", suz, S, (0, 0, 40), w, h, r.FLAG_USE_BVH)
     run("suzanne, eye 0, ONE_PIXEL_PER_LANE", suz, S, (0, 0, 0), w, h, r.FLAG_ONE_PIXEL_PER_LANE)
