@@ -161,6 +161,19 @@ RWR_API int rwr_scene_upload_mesh(rwr_context *ctx,
                                   const rwr_material_data *material,
                                   const uint8_t *rgba8_srgb, uint32_t tex_w, uint32_t tex_h);
 
+/* Extension — scenes of several meshes, each with its own material and texture (what
+ * resources::load_model_compute returns in Model{meshes, materials}; the reference's TriangleList
+ * binds meshes[0]/materials[0] only, triangle_list.rs:212-245).  Faces form one list in part order,
+ * then face order, so object ids and the lowest-index tie rule extend across parts.
+ * rwr_scene_upload_mesh == clear + add_mesh + commit. */
+RWR_API int rwr_scene_clear(rwr_context *ctx);
+RWR_API int rwr_scene_add_mesh(rwr_context *ctx,
+                               const rwr_model_vertex_small *verts, uint32_t n_verts,
+                               const rwr_model_face_small *faces, uint32_t n_faces,
+                               const rwr_material_data *material,
+                               const uint8_t *rgba8_srgb, uint32_t tex_w, uint32_t tex_h);
+RWR_API int rwr_scene_commit(rwr_context *ctx);
+
 /* Replaces Sphere::new's uniform, one per analytic sphere pass, composited in
  * array order before the mesh (src/lib.rs:532-534, 1106-1173).  n <= RWR_MAX_SPHERES. */
 RWR_API int rwr_scene_set_spheres(rwr_context *ctx, const rwr_sphere_buffer_data *spheres, uint32_t n);
@@ -237,8 +250,15 @@ RWR_API const rwr_model_vertex_small *rwr_model_vertices(const rwr_model *model)
 RWR_API const rwr_model_face_small *rwr_model_faces(const rwr_model *model);
 RWR_API const rwr_material_data *rwr_model_material(const rwr_model *model);
 RWR_API const uint8_t *rwr_model_texture_rgba8(const rwr_model *model);
-/* Convenience: rwr_scene_upload_mesh(ctx, <everything in model>). */
+/* Convenience: rwr_scene_upload_mesh(ctx, <meshes[0] / materials[0] of model>) — the reference's scene. */
 RWR_API int rwr_scene_upload_model(rwr_context *ctx, const rwr_model *model);
+/* Extension: every mesh of the model with ITS material (mesh.material, resources.rs:257). */
+RWR_API int rwr_model_part_count(const rwr_model *model, uint32_t *n_parts);
+RWR_API int rwr_model_part(const rwr_model *model, uint32_t part,
+                           const rwr_model_vertex_small **verts, uint32_t *n_verts,
+                           const rwr_model_face_small **faces, uint32_t *n_faces,
+                           rwr_material_data *material, const uint8_t **rgba8, uint32_t *tex_w, uint32_t *tex_h);
+RWR_API int rwr_scene_upload_model_all(rwr_context *ctx, const rwr_model *model);
 
 /* texture::Texture::from_bytes, src/texture.rs:98-106: decode PNG/JPEG bytes to
  * RGBA8.  *out_rgba is malloc'd; free with rwr_free(). */

@@ -189,8 +189,29 @@ def bounce_direction(n, pixel: int, sample: int, seed: int) -> np.ndarray:
     return out
 
 
+def concat_parts(parts: list) -> dict:
+    """Flattens [part, ...] (each a model dict) into one vertex/face list with a per-face material id,
+    part order then face order (the multi-material extension's face numbering)."""
+    from . import ref_loader as rl
+    verts = np.concatenate([p["vertices"] for p in parts]) if parts else np.zeros(0, rl.VERTEX_DTYPE)
+    faces, fmat, off = [], [], 0
+    for k, p in enumerate(parts):
+        f = p["faces"].copy()
+        f["indices"] += off
+        off += len(p["vertices"])
+        faces.append(f)
+        fmat.append(np.full(len(f), k, np.uint32))
+    return {"vertices": verts, "faces": np.concatenate(faces) if faces else np.zeros(0, rl.FACE_DTYPE),
+            "face_material": np.concatenate(fmat) if fmat else np.zeros(0, np.uint32),
+            "materials": np.concatenate([p["material"] for p in parts]),
+            "textures": [np.ascontiguousarray(p["texture"]) for p in parts]}
+
+
 def render_path(cam_inv, screen, params, spheres, model, instances=None, rows=None) -> dict:
-    """The extended integrator (spp / one bounce / instances) on the CPU, brute force."""
+    """The extended integrator (spp / one bounce / instances / several materials) on the CPU, brute
+    force.  `model` is one model dict or a list of them (parts)."""
+    if isinstance(model, (list, tuple)):
+        return _render_path_mm(cam_inv, screen, params, spheres, concat_parts(list(model)), instances, rows)
     w, h = int(screen["width"][0]), int(screen["height"][0])
     r0, r1 = rows if rows is not None else (0, h)
     color = np.zeros((h, w, 4), np.uint8)
@@ -210,6 +231,34 @@ def render_path(cam_inv, screen, params, spheres, model, instances=None, rows=No
            C.c_uint32(r0), C.c_uint32(r1), _p(color), _p(depth), _p(color_f), _p(obj_id), _p(hit_t))
     if rc != 0:
         raise MemoryError("or_render_path")
+    return {"color": color, "depth": depth, "color_f32": color_f, "obj_id": obj_id, "hit_t": hit_t}
+
+
+def _render_path_mm(cam_inv, screen, params, spheres, scene, instances, rows) -> dict:
+    w, h = int(screen["width"][0]), int(screen["height"][0])
+    r0, r1 = rows if rows is not None else (0, h)
+    color = np.zeros((h, w, 4), np.uint8)
+    depth = np.zeros((h, w), np.float32)
+    color_f = np.zeros((h, w, 4), np.float32)
+    obj_id = np.full((h, w), -1, np.int32)
+    hit_t = np.zeros((h, w), np.float32)
+    texs = scene["textures"]
+    n_mat = len(texs)
+    ptrs = (C.c_void_p * n_mat)(*[t.ctypes.data for t in texs])
+    ws = np.array([t.shape[1] for t in texs], np.uint32)
+    hs = np.array([t.shape[0] for t in texs], np.uint32)
+    n_inst = 0 if instances is None else len(instances)
+    inst = None if n_inst == 0 else np.ascontiguousarray(instances, dtype=INSTANCE_DTYPE)
+    mats = np.ascontiguousarray(scene["materials"])
+    fmat = np.ascontiguousarray(scene["face_material"], dtype=np.uint32)
+    f = lib().or_render_path_mm
+    f.restype = C.c_int
+    rc = f(_p(cam_inv), _p(screen), _p(params), _p(spheres), C.c_uint32(len(spheres)),
+           _p(scene["vertices"]), C.c_uint32(len(scene["vertices"])), _p(scene["faces"]), C.c_uint32(len(scene["faces"])),
+           _p(inst), C.c_uint32(n_inst), _p(mats), C.c_uint32(n_mat), _p(fmat), ptrs, _p(ws), _p(hs),
+           C.c_uint32(r0), C.c_uint32(r1), _p(color), _p(depth), _p(color_f), _p(obj_id), _p(hit_t))
+    if rc != 0:
+        raise MemoryError("or_render_path_mm")
     return {"color": color, "depth": depth, "color_f32": color_f, "obj_id": obj_id, "hit_t": hit_t}
 
 

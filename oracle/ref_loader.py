@@ -170,6 +170,37 @@ def decode_image_rgba8(path: str) -> np.ndarray:
         return np.ascontiguousarray(np.asarray(im.convert("RGBA"), dtype=np.uint8))
 
 
+def load_model_parts(res_dir: str, file_name: str) -> list:
+    """EXTENSION: every mesh of the file with ITS material (mesh.material, resources.rs:257), as a list
+    of model dicts — what a renderer that consumed all of Model{meshes, materials} would draw."""
+    with open(os.path.join(res_dir, file_name), "r") as fh:
+        meshes, mtllibs, mesh_mtl = parse_obj(fh.read())
+    materials: list[RefMaterial] = []
+    for lib in mtllibs:
+        with open(os.path.join(res_dir, lib), "r") as fh:
+            materials.extend(parse_mtl(fh.read()))
+    parts = []
+    for m, mtl_name in zip(meshes, mesh_mtl):
+        n_verts = len(m.positions) // 3
+        if len(m.texcoords) < 2 * n_verts:
+            raise IndexError("mesh has no texture coordinates (resources.rs:226 index panic)")
+        mid = 0
+        for k, mat in enumerate(materials):
+            if mat.name == mtl_name:
+                mid = k
+        mat0 = materials[mid]
+        verts = np.zeros(n_verts, dtype=VERTEX_DTYPE)
+        verts["position"] = np.asarray(m.positions, dtype=np.float32).reshape(-1, 3)
+        verts["tex_coords"] = np.asarray(m.texcoords, dtype=np.float32).reshape(-1, 2)
+        faces = np.zeros(len(m.indices) // 3, dtype=FACE_DTYPE)
+        faces["indices"] = np.asarray(m.indices, dtype=np.uint32).reshape(-1, 3)
+        material = np.zeros(1, dtype=MATERIAL_DTYPE)
+        material["ambient"], material["diffuse"], material["specular"] = mat0.ambient, mat0.diffuse, mat0.specular
+        parts.append({"vertices": verts, "faces": faces, "material": material,
+                      "texture": decode_image_rgba8(os.path.join(res_dir, mat0.diffuse_texture))})
+    return parts
+
+
 def load_model_compute(res_dir: str, file_name: str) -> dict:
     """resources.rs:163-264.  Only meshes[0]/materials[0] are consumed downstream
     (triangle_list.rs:212-245), and that is what is returned."""

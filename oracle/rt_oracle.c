@@ -285,6 +285,12 @@ typedef struct {
     const OrFace *faces;   uint32_t n_faces;
     const OrMaterial *material;
     Tex tex;
+    /* EXTENSION (multi-material scenes; the reference consumes materials[0] only,
+     * triangle_list.rs:212): when face_material != NULL, face i is shaded with
+     * materials[face_material[i % n_base_faces]] / texs[...] instead of material / tex. */
+    const uint32_t *face_material; uint32_t n_base_faces;
+    const OrMaterial *materials;
+    const Tex *texs;
 } Mesh;
 
 /* Local shading of a mesh hit — triangle_list/compute.wgsl:217-234.
@@ -300,7 +306,14 @@ static inline v3 shade_mesh(const Mesh *m, uint32_t i_min, const HitRecord *h, R
     float tu = h->barycentric.x * tc0[0] + h->barycentric.y * tc1[0] + h->barycentric.z * tc2[0];
     float tv = h->barycentric.x * tc0[1] + h->barycentric.y * tc1[1] + h->barycentric.z * tc2[1];
     tv = 1.0f - tv;
-    v3 tex = tex_sample_bilinear(&m->tex, tu, tv);
+    const OrMaterial *mat = m->material;
+    const Tex *tx = &m->tex;
+    if (m->face_material) {
+        const uint32_t mid = m->face_material[i_min % m->n_base_faces];
+        mat = &m->materials[mid];
+        tx = &m->texs[mid];
+    }
+    v3 tex = tex_sample_bilinear(tx, tu, tv);
     if (albedo) *albedo = tex;
 
     v3 nl = neg3(normalize3(kLightDir));
@@ -308,11 +321,11 @@ static inline v3 shade_mesh(const Mesh *m, uint32_t i_min, const HitRecord *h, R
     v3 diffuse = scale3(tex, ndl);
     v3 half_dir = normalize3(sub3(nl, ray.direction));
     float sp = powf(fmaxf(0.0f, dot3(half_dir, h->normal)), 32.0f);
-    v3 specular = V3(m->material->specular[0] * sp, m->material->specular[1] * sp, m->material->specular[2] * sp);
+    v3 specular = V3(mat->specular[0] * sp, mat->specular[1] * sp, mat->specular[2] * sp);
     v3 out;
-    out.x = (m->material->ambient[0] + diffuse.x) + specular.x;
-    out.y = (m->material->ambient[1] + diffuse.y) + specular.y;
-    out.z = (m->material->ambient[2] + diffuse.z) + specular.z;
+    out.x = (mat->ambient[0] + diffuse.x) + specular.x;
+    out.y = (mat->ambient[1] + diffuse.y) + specular.y;
+    out.z = (mat->ambient[2] + diffuse.z) + specular.z;
     return out;
 }
 
@@ -412,6 +425,7 @@ OR_API void or_mesh_pass(const OrCameraInvUniform *cam, const OrScreen *screen,
     Mesh m;
     m.verts = verts; m.n_verts = n_verts; m.faces = faces; m.n_faces = n_faces; m.material = material;
     m.tex.rgba = tex_rgba8; m.tex.w = tex_w; m.tex.h = tex_h;
+    m.face_material = NULL; m.n_base_faces = n_faces; m.materials = NULL; m.texs = NULL;
     build_srgb_lut(m.tex.lut);
     OrAux aux = {color_u8, color_f32, obj_id, hit_t};
     const int W = (int)screen->width, H = (int)screen->height;
@@ -567,14 +581,28 @@ static inline v3 shade_any(const Scene *sc, int32_t id, const HitRecord *h, Ray 
     return shade_sphere(h, ray, albedo);
 }
 
-OR_API int or_render_path(const OrCameraInvUniform *cam, const OrScreen *screen, const OrRenderParams *params,
-                          const OrSphere *spheres, uint32_t n_spheres,
-                          const OrVertex *verts, uint32_t n_verts, const OrFace *faces, uint32_t n_faces,
-                          const OrInstance *instances, uint32_t n_instances,
-                          const OrMaterial *material, const uint8_t *tex_rgba8, uint32_t tex_w, uint32_t tex_h,
-                          uint32_t row_begin, uint32_t row_end,
-                          uint8_t *color_u8, float *depth_out, float *color_f32, int32_t *obj_id, float *hit_t)
+/* Multi-material form: face i (before instancing) uses materials[face_material[i]] and the
+ * texture (tex_ptrs[k], tex_ws[k], tex_hs[k]) of that material; face_material == NULL means
+ * "everything uses material 0".  Faces of all parts are one flat list (part order, then face
+ * order), so the lowest-index tie rule extends across parts. */
+OR_API int or_render_path_mm(const OrCameraInvUniform *cam, const OrScreen *screen, const OrRenderParams *params,
+                             const OrSphere *spheres, uint32_t n_spheres,
+                             const OrVertex *verts, uint32_t n_verts, const OrFace *faces, uint32_t n_faces,
+                             const OrInstance *instances, uint32_t n_instances,
+                             const OrMaterial *materials, uint32_t n_materials, const uint32_t *face_material,
+                             const uint8_t *const *tex_ptrs, const uint32_t *tex_ws, const uint32_t *tex_hs,
+                             uint32_t row_begin, uint32_t row_end,
+                             uint8_t *color_u8, float *depth_out, float *color_f32, int32_t *obj_id, float *hit_t)
 {
+    const OrMaterial *material = materials;
+    const uint8_t *tex_rgba8 = n_materials ? tex_ptrs[0] : NULL;
+    const uint32_t tex_w = n_materials ? tex_ws[0] : 0u, tex_h = n_materials ? tex_hs[0] : 0u;
+    Tex *texs = (Tex *)calloc(n_materials ? n_materials : 1u, sizeof(Tex));
+    if (!texs) return -1;
+    for (uint32_t k = 0; k < n_materials; k++) {
+        texs[k].rgba = tex_ptrs[k]; texs[k].w = tex_ws[k]; texs[k].h = tex_hs[k];
+        build_srgb_lut(texs[k].lut);
+    }
     const uint32_t W = screen->width, H = screen->height;
     if (row_end > H) row_end = H;
     /* flatten instances */
@@ -584,10 +612,14 @@ OR_API int or_render_path(const OrCameraInvUniform *cam, const OrScreen *screen,
     sc.mesh.material = material;
     sc.mesh.tex.rgba = tex_rgba8; sc.mesh.tex.w = tex_w; sc.mesh.tex.h = tex_h;
     build_srgb_lut(sc.mesh.tex.lut);
+    sc.mesh.face_material = (n_materials > 1) ? face_material : NULL;
+    sc.mesh.n_base_faces = n_faces ? n_faces : 1u;
+    sc.mesh.materials = materials;
+    sc.mesh.texs = texs;
     if (n_instances && n_faces) {
         wverts = (OrVertex *)malloc((size_t)n_verts * n_instances * sizeof(OrVertex));
         wfaces = (OrFace *)malloc((size_t)n_faces * n_instances * sizeof(OrFace));
-        if (!wverts || !wfaces) { free(wverts); free(wfaces); return -1; }
+        if (!wverts || !wfaces) { free(wverts); free(wfaces); free(texs); return -1; }
         for (uint32_t k = 0; k < n_instances; k++) {
             for (uint32_t i = 0; i < n_verts; i++) {
                 OrVertex v = verts[i];
@@ -680,8 +712,22 @@ OR_API int or_render_path(const OrCameraInvUniform *cam, const OrScreen *screen,
             if (hit_t) hit_t[idx] = t0;
         }
     }
-    free(wverts); free(wfaces);
+    free(wverts); free(wfaces); free(texs);
     return 0;
+}
+
+OR_API int or_render_path(const OrCameraInvUniform *cam, const OrScreen *screen, const OrRenderParams *params,
+                          const OrSphere *spheres, uint32_t n_spheres,
+                          const OrVertex *verts, uint32_t n_verts, const OrFace *faces, uint32_t n_faces,
+                          const OrInstance *instances, uint32_t n_instances,
+                          const OrMaterial *material, const uint8_t *tex_rgba8, uint32_t tex_w, uint32_t tex_h,
+                          uint32_t row_begin, uint32_t row_end,
+                          uint8_t *color_u8, float *depth_out, float *color_f32, int32_t *obj_id, float *hit_t)
+{
+    const uint8_t *ptrs[1] = {tex_rgba8};
+    return or_render_path_mm(cam, screen, params, spheres, n_spheres, verts, n_verts, faces, n_faces, instances, n_instances,
+                             material, 1u, NULL, ptrs, &tex_w, &tex_h, row_begin, row_end, color_u8, depth_out, color_f32,
+                             obj_id, hit_t);
 }
 
 /* Single-ray probes used by the known-answer tests. */

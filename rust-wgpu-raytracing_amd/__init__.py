@@ -92,6 +92,9 @@ def lib() -> C.CDLL:
         "rwr_ctx_create": [i32, vp], "rwr_ctx_destroy": [vp], "rwr_device_count": [vp],
         "rwr_ctx_device_info": [vp, vp, C.c_size_t, vp, vp], "rwr_ctx_set_stream": [vp, vp], "rwr_ctx_get_stream": [vp],
         "rwr_scene_upload_mesh": [vp, vp, u32, vp, u32, vp, vp, u32, u32],
+        "rwr_scene_clear": [vp], "rwr_scene_add_mesh": [vp, vp, u32, vp, u32, vp, vp, u32, u32], "rwr_scene_commit": [vp],
+        "rwr_model_part_count": [vp, vp], "rwr_model_part": [vp, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+        "rwr_scene_upload_model_all": [vp, vp],
         "rwr_scene_set_spheres": [vp, vp, u32], "rwr_scene_set_instances": [vp, vp, u32],
         "rwr_resize": [vp, vp], "rwr_render": [vp, vp, vp], "rwr_render_rows": [vp, vp, vp, u32, u32],
         "rwr_synchronize": [vp], "rwr_readback": [vp, vp, vp, vp, vp, vp], "rwr_get_device_targets": [vp, vp, vp],
@@ -208,6 +211,31 @@ def load_model_compute(file_name: str, res_dir: str = RES_DIR) -> dict:
             "n_meshes": n_meshes, "n_materials": n_materials}
 
 
+def load_model_parts(file_name: str, res_dir: str = RES_DIR) -> list:
+    """Extension: every mesh of the file with its own material, as a list of model dicts."""
+    L = lib()
+    h = C.c_void_p()
+    _check(L.rwr_load_model_compute(res_dir.encode(), file_name.encode(), C.byref(h)))
+    parts = []
+    try:
+        n = C.c_uint32()
+        _check(L.rwr_model_part_count(h, C.byref(n)))
+        for i in range(n.value):
+            pv, pf, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            nv, nf, tw, th = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+            mat = np.zeros(1, dtype=MATERIAL_DTYPE)
+            _check(L.rwr_model_part(h, i, C.byref(pv), C.byref(nv), C.byref(pf), C.byref(nf), _p(mat), C.byref(pt), C.byref(tw), C.byref(th)))
+            parts.append({
+                "vertices": np.frombuffer(C.string_at(pv, nv.value * 32), dtype=VERTEX_DTYPE).copy(),
+                "faces": np.frombuffer(C.string_at(pf, nf.value * 16), dtype=FACE_DTYPE).copy(),
+                "material": mat,
+                "texture": np.frombuffer(C.string_at(pt, tw.value * th.value * 4), dtype=np.uint8).reshape(th.value, tw.value, 4).copy(),
+            })
+    finally:
+        L.rwr_model_free(h)
+    return parts
+
+
 # ------------------------------------------------------------------------ context --
 def device_count() -> int:
     n = C.c_int()
@@ -260,6 +288,19 @@ class Context:
 
     def upload_model(self, model: dict):
         self.upload_mesh(model["vertices"], model["faces"], model["material"], model["texture"])
+
+    def upload_parts(self, parts: list):
+        """Extension: a scene of several meshes, each with its own material and texture."""
+        _check(lib().rwr_scene_clear(self._h))
+        for m in parts:
+            vertices = np.ascontiguousarray(m["vertices"], dtype=VERTEX_DTYPE)
+            faces = np.ascontiguousarray(m["faces"], dtype=FACE_DTYPE)
+            material = np.ascontiguousarray(m["material"], dtype=MATERIAL_DTYPE)
+            texture = np.ascontiguousarray(m["texture"], dtype=np.uint8)
+            th, tw = texture.shape[:2]
+            _check(lib().rwr_scene_add_mesh(self._h, _p(vertices), len(vertices), _p(faces), len(faces), _p(material),
+                                            _p(texture), tw, th))
+        _check(lib().rwr_scene_commit(self._h))
 
     def set_spheres(self, spheres):
         spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)

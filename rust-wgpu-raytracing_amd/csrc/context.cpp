@@ -91,7 +91,15 @@ struct rwr_context {
     uint32_t last_segments = 0;
     uint32_t last_spp = 0;
     bool last_had_bounce = false;
-    DeviceBuffer<float4> d_tex;   // texels decoded to linear f32 at upload (Rgba8UnormSrgb semantics)
+    // one decoded texture per scene part (texels decoded to linear f32 at upload, Rgba8UnormSrgb semantics)
+    std::vector<DeviceBuffer<float4>> d_texs;
+    DeviceBuffer<uint32_t> d_face_mat;      // per face: index of its part's material
+    DeviceBuffer<MaterialRec> d_materials;
+    // host staging of the scene being assembled (rwr_scene_clear / add_mesh / commit)
+    std::vector<rwr_model_vertex_small> st_verts;
+    std::vector<rwr_model_face_small> st_faces;
+    std::vector<uint32_t> st_face_mat;
+    std::vector<MaterialRec> st_materials;
     uint32_t n_verts = 0, n_faces = 0, n_instances = 0, n_tris = 0;
     uint32_t tex_w = 0, tex_h = 0;
     rwr_material_data material{};
@@ -252,7 +260,7 @@ int rebuild_tris(rwr_context *ctx)
     RWR_HIP_CHECK(ctx->d_face_uv.ensure(total));
     RWR_HIP_CHECK(ctx->d_cull.ensure(total));
     RWR_HIP_CHECK(ctx->d_ftris.ensure(total));
-    RWR_HIP_CHECK(launch_prebake(ctx->stream, ctx->d_verts.ptr, ctx->d_faces.ptr, ctx->n_faces, ctx->d_instances.ptr,
+    RWR_HIP_CHECK(launch_prebake(ctx->stream, ctx->d_verts.ptr, ctx->d_faces.ptr, ctx->d_face_mat.ptr, ctx->n_faces, ctx->d_instances.ptr,
                                  ctx->n_instances, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_cull.ptr));
     // BVH for incoherent rays, built on the host from the device's own world-space corners
     // (so instancing arithmetic happens in exactly one place, k_prebake)
@@ -338,7 +346,8 @@ void rwr_ctx_destroy(rwr_context *ctx)
     ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
     ctx->d_tris.release(); ctx->d_face_uv.release(); ctx->d_cull.release(); ctx->d_ftris.release(); ctx->d_bin_lists.release(); ctx->d_bin_counts.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
-    ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_seg_count.release(); ctx->d_seg_total.release(); ctx->d_tex.release();
+    ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_seg_count.release(); ctx->d_seg_total.release(); for (auto &t : ctx->d_texs) t.release();
+    ctx->d_face_mat.release(); ctx->d_materials.release();
     ctx->d_color.release(); ctx->d_depth.release(); ctx->d_color_f32.release();
     ctx->d_obj_id.release(); ctx->d_hit_t.release();
     for (hipEvent_t e : ctx->timing_events) (void)hipEventDestroy(e);
@@ -372,57 +381,108 @@ int rwr_ctx_set_stream(rwr_context *ctx, void *hip_stream)
 
 void *rwr_ctx_get_stream(rwr_context *ctx) { return ctx ? reinterpret_cast<void *>(ctx->stream) : nullptr; }
 
-int rwr_scene_upload_mesh(rwr_context *ctx, const rwr_model_vertex_small *verts, uint32_t n_verts,
-                          const rwr_model_face_small *faces, uint32_t n_faces, const rwr_material_data *material,
-                          const uint8_t *rgba8_srgb, uint32_t tex_w, uint32_t tex_h)
+int rwr_scene_clear(rwr_context *ctx)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
-    if (n_faces > 0) {
-        if (!verts || !faces || !material || !rgba8_srgb)
-            return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL mesh array with n_faces = %u", n_faces);
-        if (n_verts == 0 || tex_w == 0 || tex_h == 0)
-            return set_error(RWR_ERR_INVALID_ARGUMENT, "empty vertex array or texture with n_faces = %u", n_faces);
-        // The shader indexes vertice_list unchecked (compute.wgsl:191-193); an
-        // out-of-range index would be a GPU fault here, so it is rejected up front.
-        for (uint32_t f = 0; f < n_faces; f++)
-            for (int k = 0; k < 3; k++)
-                if (faces[f].indices[k] >= n_verts)
-                    return set_error(RWR_ERR_INVALID_ARGUMENT, "face %u index %u out of range (n_verts %u)", f,
-                                     faces[f].indices[k], n_verts);
-        if ((uint64_t)n_faces * (ctx->n_instances ? ctx->n_instances : 1u) > 0x7fffffffull)
-            return set_error(RWR_ERR_INVALID_ARGUMENT, "too many faces");
-    }
     DeviceGuard g(ctx->device);
     RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->st_verts.clear(); ctx->st_faces.clear(); ctx->st_face_mat.clear(); ctx->st_materials.clear();
+    for (auto &t : ctx->d_texs) t.release();
+    ctx->d_texs.clear();
     ctx->have_mesh = false;
-    ctx->n_faces = n_faces;
-    ctx->n_verts = n_verts;
-    ctx->n_tris = 0;
-    if (n_faces == 0) {
-        ctx->have_mesh = true;
-        ctx->tris_dirty = false;
-        return RWR_OK;
-    }
-    RWR_HIP_CHECK(ctx->d_verts.ensure(n_verts));
-    RWR_HIP_CHECK(ctx->d_faces.ensure(n_faces));
-    RWR_HIP_CHECK(ctx->d_tex.ensure((size_t)tex_w * tex_h));
-    RWR_HIP_CHECK(hipMemcpy(ctx->d_verts.ptr, verts, (size_t)n_verts * sizeof *verts, hipMemcpyHostToDevice));
-    RWR_HIP_CHECK(hipMemcpy(ctx->d_faces.ptr, faces, (size_t)n_faces * sizeof *faces, hipMemcpyHostToDevice));
-    {
+    ctx->n_faces = ctx->n_verts = ctx->n_tris = 0;
+    return RWR_OK;
+}
+
+int rwr_scene_add_mesh(rwr_context *ctx, const rwr_model_vertex_small *verts, uint32_t n_verts,
+                       const rwr_model_face_small *faces, uint32_t n_faces, const rwr_material_data *material,
+                       const uint8_t *rgba8_srgb, uint32_t tex_w, uint32_t tex_h)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (n_faces == 0) return RWR_OK;  // nothing to add
+    if (!verts || !faces || !material || !rgba8_srgb)
+        return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL mesh array with n_faces = %u", n_faces);
+    if (n_verts == 0 || tex_w == 0 || tex_h == 0)
+        return set_error(RWR_ERR_INVALID_ARGUMENT, "empty vertex array or texture with n_faces = %u", n_faces);
+    // The shader indexes vertice_list unchecked (compute.wgsl:191-193); an
+    // out-of-range index would be a GPU fault here, so it is rejected up front.
+    for (uint32_t f = 0; f < n_faces; f++)
+        for (int k = 0; k < 3; k++)
+            if (faces[f].indices[k] >= n_verts)
+                return set_error(RWR_ERR_INVALID_ARGUMENT, "face %u index %u out of range (n_verts %u)", f, faces[f].indices[k], n_verts);
+    const uint64_t total_faces = (uint64_t)ctx->st_faces.size() + n_faces;
+    if (total_faces * (ctx->n_instances ? ctx->n_instances : 1u) > 0x7fffffffull || (uint64_t)ctx->st_verts.size() + n_verts > 0xffffffffull)
+        return set_error(RWR_ERR_INVALID_ARGUMENT, "too many faces or vertices");
+    DeviceGuard g(ctx->device);
+    // texture -> linear float4 on the device
+    ctx->d_texs.emplace_back();
+    DeviceBuffer<float4> &tex = ctx->d_texs.back();
+    hipError_t e = tex.ensure((size_t)tex_w * tex_h);
+    if (e == hipSuccess) {
         float lut[256];
         build_srgb_lut(lut);
         std::vector<float4> lin((size_t)tex_w * tex_h);
         for (size_t i = 0; i < lin.size(); i++)
             lin[i] = make_float4(lut[rgba8_srgb[4 * i]], lut[rgba8_srgb[4 * i + 1]], lut[rgba8_srgb[4 * i + 2]],
                                  (float)rgba8_srgb[4 * i + 3] / 255.0f);  // alpha is linear in sRGB formats
-        RWR_HIP_CHECK(hipMemcpy(ctx->d_tex.ptr, lin.data(), lin.size() * sizeof(float4), hipMemcpyHostToDevice));
+        e = hipMemcpy(tex.ptr, lin.data(), lin.size() * sizeof(float4), hipMemcpyHostToDevice);
     }
-    ctx->material = *material;
-    ctx->tex_w = tex_w;
-    ctx->tex_h = tex_h;
+    if (e != hipSuccess) {
+        ctx->d_texs.back().release();
+        ctx->d_texs.pop_back();
+        return set_error(RWR_ERR_HIP, "texture upload failed: %s", hipGetErrorString(e));
+    }
+    const uint32_t vbase = (uint32_t)ctx->st_verts.size(), mid = (uint32_t)ctx->st_materials.size();
+    ctx->st_verts.insert(ctx->st_verts.end(), verts, verts + n_verts);
+    for (uint32_t f = 0; f < n_faces; f++) {
+        rwr_model_face_small fc = faces[f];
+        fc.indices[0] += vbase; fc.indices[1] += vbase; fc.indices[2] += vbase;
+        ctx->st_faces.push_back(fc);
+        ctx->st_face_mat.push_back(mid);
+    }
+    MaterialRec M{};
+    for (int k = 0; k < 3; k++) { M.ambient[k] = material->ambient[k]; M.specular[k] = material->specular[k]; }
+    M.tex_w = tex_w; M.tex_h = tex_h; M.tex = tex.ptr;
+    ctx->st_materials.push_back(M);
+    if (mid == 0) ctx->material = *material;
+    return RWR_OK;
+}
+
+int rwr_scene_commit(rwr_context *ctx)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->n_faces = (uint32_t)ctx->st_faces.size();
+    ctx->n_verts = (uint32_t)ctx->st_verts.size();
+    ctx->n_tris = 0;
     ctx->have_mesh = true;
+    if (ctx->n_faces == 0) {
+        ctx->tris_dirty = false;
+        return RWR_OK;
+    }
+    RWR_HIP_CHECK(ctx->d_verts.ensure(ctx->n_verts));
+    RWR_HIP_CHECK(ctx->d_faces.ensure(ctx->n_faces));
+    RWR_HIP_CHECK(ctx->d_face_mat.ensure(ctx->n_faces));
+    RWR_HIP_CHECK(ctx->d_materials.ensure(ctx->st_materials.size()));
+    RWR_HIP_CHECK(hipMemcpy(ctx->d_verts.ptr, ctx->st_verts.data(), ctx->st_verts.size() * sizeof(rwr_model_vertex_small), hipMemcpyHostToDevice));
+    RWR_HIP_CHECK(hipMemcpy(ctx->d_faces.ptr, ctx->st_faces.data(), ctx->st_faces.size() * sizeof(rwr_model_face_small), hipMemcpyHostToDevice));
+    RWR_HIP_CHECK(hipMemcpy(ctx->d_face_mat.ptr, ctx->st_face_mat.data(), ctx->st_face_mat.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RWR_HIP_CHECK(hipMemcpy(ctx->d_materials.ptr, ctx->st_materials.data(), ctx->st_materials.size() * sizeof(MaterialRec), hipMemcpyHostToDevice));
+    ctx->tex_w = ctx->st_materials[0].tex_w;
+    ctx->tex_h = ctx->st_materials[0].tex_h;
     ctx->tris_dirty = true;
     return rebuild_tris(ctx);
+}
+
+int rwr_scene_upload_mesh(rwr_context *ctx, const rwr_model_vertex_small *verts, uint32_t n_verts,
+                          const rwr_model_face_small *faces, uint32_t n_faces, const rwr_material_data *material,
+                          const uint8_t *rgba8_srgb, uint32_t tex_w, uint32_t tex_h)
+{
+    int rc = rwr_scene_clear(ctx);
+    if (rc == RWR_OK) rc = rwr_scene_add_mesh(ctx, verts, n_verts, faces, n_faces, material, rgba8_srgb, tex_w, tex_h);
+    if (rc == RWR_OK) rc = rwr_scene_commit(ctx);
+    return rc;
 }
 
 int rwr_scene_set_spheres(rwr_context *ctx, const rwr_sphere_buffer_data *spheres, uint32_t n)
@@ -519,6 +579,9 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         fp.ambient[k] = ctx->material.ambient[k];
         fp.specular[k] = ctx->material.specular[k];
     }
+    fp.materials = ctx->d_materials.ptr;
+    fp.n_materials = (uint32_t)ctx->st_materials.size();
+    const float4 *tex0 = ctx->d_texs.empty() ? nullptr : ctx->d_texs[0].ptr;
     Targets tg{ctx->d_color.ptr, ctx->d_depth.ptr, aux ? ctx->d_color_f32.ptr : nullptr,
                aux ? ctx->d_obj_id.ptr : nullptr, aux ? ctx->d_hit_t.ptr : nullptr};
     CullConsts cc;
@@ -562,13 +625,13 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     if (time_this && !dispatch_timed) RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs], ctx->stream));
     if (!wavefront && (rp.flags & RWR_FLAG_USE_BVH)) {
         const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
-        RWR_HIP_CHECK(launch_primary_bvh(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, bvh_p, ctx->d_tex.ptr, tg));
+        RWR_HIP_CHECK(launch_primary_bvh(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, bvh_p, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront) {
         if ((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel)
-            RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, tg));
+            RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, tex0, tg));
         else
-            RWR_HIP_CHECK(launch_primary_p2(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr, tg,
+            RWR_HIP_CHECK(launch_primary_p2(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, tex0, tg,
                                             dispatch_timed ? ctx->timing_events[2 * ctx->timing_pairs] : nullptr,
                                             dispatch_timed ? ctx->timing_events[2 * ctx->timing_pairs + 1] : nullptr));
         ctx->last_spp = 0;
@@ -588,10 +651,10 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
         for (uint32_t sidx = 0; sidx < rp.spp; sidx++) {
             fp.sample = sidx;
-            RWR_HIP_CHECK(launch_wf_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, ctx->d_tex.ptr,
+            RWR_HIP_CHECK(launch_wf_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, tex0,
                                             tg, wf));
             if (rp.max_bounces)
-                RWR_HIP_CHECK(launch_wf_bounce(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, bvh, ctx->d_tex.ptr,
+                RWR_HIP_CHECK(launch_wf_bounce(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, bvh, tex0,
                                                wf, n_segments));
         }
         RWR_HIP_CHECK(launch_wf_resolve(ctx->stream, fp, tg, wf));

@@ -93,6 +93,51 @@ const rwr_material_data *rwr_model_material(const rwr_model *model)
     return &md;
 }
 
+int rwr_model_part_count(const rwr_model *model, uint32_t *n_parts)
+{
+    if (!model || !n_parts) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *n_parts = (uint32_t)model->model.meshes.size();
+    return RWR_OK;
+}
+
+int rwr_model_part(const rwr_model *model, uint32_t part, const rwr_model_vertex_small **verts, uint32_t *n_verts,
+                   const rwr_model_face_small **faces, uint32_t *n_faces, rwr_material_data *material,
+                   const uint8_t **rgba8, uint32_t *tex_w, uint32_t *tex_h)
+{
+    if (!model) return set_error(RWR_ERR_INVALID_ARGUMENT, "model is NULL");
+    const auto &m = model->model;
+    if (part >= m.meshes.size()) return set_error(RWR_ERR_INVALID_ARGUMENT, "part %u out of range (%zu meshes)", part, m.meshes.size());
+    const auto &mesh = m.meshes[part];
+    if (mesh.material >= m.materials.size()) return set_error(RWR_ERR_PARSE, "mesh %u references material %zu of %zu", part, mesh.material, m.materials.size());
+    const auto &mat = m.materials[mesh.material];   // mesh.material = material_id.unwrap_or(0), resources.rs:257
+    if (verts) *verts = mesh.vertex_buffer.data();
+    if (n_verts) *n_verts = (uint32_t)mesh.vertex_buffer.size();
+    if (faces) *faces = mesh.index_buffer.data();
+    if (n_faces) *n_faces = (uint32_t)mesh.index_buffer.size();
+    if (material)
+        *material = rwr_material_data{{mat.ambient[0], mat.ambient[1], mat.ambient[2]}, 0.0f, {mat.diffuse[0], mat.diffuse[1], mat.diffuse[2]}, 0.0f,
+                                      {mat.specular[0], mat.specular[1], mat.specular[2]}, 0.0f};
+    if (rgba8) *rgba8 = mat.diffuse_texture.rgba.data();
+    if (tex_w) *tex_w = mat.diffuse_texture.width;
+    if (tex_h) *tex_h = mat.diffuse_texture.height;
+    return RWR_OK;
+}
+
+int rwr_scene_upload_model_all(rwr_context *ctx, const rwr_model *model)
+{
+    if (!ctx || !model) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = rwr_scene_clear(ctx);
+    for (uint32_t i = 0; rc == RWR_OK && i < model->model.meshes.size(); i++) {
+        const rwr_model_vertex_small *v; const rwr_model_face_small *f; const uint8_t *t;
+        uint32_t nv, nf, tw, th;
+        rwr_material_data md;
+        rc = rwr_model_part(model, i, &v, &nv, &f, &nf, &md, &t, &tw, &th);
+        if (rc == RWR_OK) rc = rwr_scene_add_mesh(ctx, v, nv, f, nf, &md, t, tw, th);
+    }
+    if (rc == RWR_OK) rc = rwr_scene_commit(ctx);
+    return rc;
+}
+
 int rwr_scene_upload_model(rwr_context *ctx, const rwr_model *model)
 {
     if (!ctx || !model) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");

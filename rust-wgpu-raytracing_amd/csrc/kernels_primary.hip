@@ -32,7 +32,8 @@ namespace rwr {
 // -> TriRecord[] + FaceUV[].  One thread per (instance, face).
 __global__ void __launch_bounds__(256)
 k_prebake(const rwr_model_vertex_small *__restrict__ verts, const rwr_model_face_small *__restrict__ faces,
-          uint32_t n_faces, const rwr_instance_raw *__restrict__ instances, uint32_t n_instances,
+          const uint32_t *__restrict__ face_material, uint32_t n_faces, const rwr_instance_raw *__restrict__ instances,
+          uint32_t n_instances,
           TriRecord *__restrict__ tris, FaceUV *__restrict__ face_uv, CullRec *__restrict__ cull)
 {
     const uint32_t total = n_faces * (n_instances ? n_instances : 1u);
@@ -70,7 +71,8 @@ k_prebake(const rwr_model_vertex_small *__restrict__ verts, const rwr_model_face
     U.uv0[0] = v0.tex_coords[0]; U.uv0[1] = v0.tex_coords[1];
     U.uv1[0] = v1.tex_coords[0]; U.uv1[1] = v1.tex_coords[1];
     U.uv2[0] = v2.tex_coords[0]; U.uv2[1] = v2.tex_coords[1];
-    U.pad[0] = U.pad[1] = 0.0f;
+    U.material = face_material ? face_material[f] : 0u;
+    U.pad = 0.0f;
     face_uv[i] = U;
     CullRec R;
     R.p0[0] = p0.x; R.p0[1] = p0.y; R.p0[2] = p0.z;
@@ -81,13 +83,13 @@ k_prebake(const rwr_model_vertex_small *__restrict__ verts, const rwr_model_face
 }
 
 hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, const rwr_model_face_small *faces,
-                          uint32_t n_faces, const rwr_instance_raw *instances, uint32_t n_instances,
-                          TriRecord *tris, FaceUV *face_uv, CullRec *cull)
+                          const uint32_t *face_material, uint32_t n_faces, const rwr_instance_raw *instances,
+                          uint32_t n_instances, TriRecord *tris, FaceUV *face_uv, CullRec *cull)
 {
     const uint32_t total = n_faces * (n_instances ? n_instances : 1u);
     if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_prebake, dim3((total + 255) / 256), dim3(256), 0, s, verts, faces, n_faces, instances,
-                       n_instances, tris, face_uv, cull);
+    hipLaunchKernelGGL(k_prebake, dim3((total + 255) / 256), dim3(256), 0, s, verts, faces, face_material, n_faces,
+                       instances, n_instances, tris, face_uv, cull);
     return hipGetLastError();
 }
 

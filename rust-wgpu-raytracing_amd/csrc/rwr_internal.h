@@ -40,8 +40,18 @@ static_assert(sizeof(TriRecord) == 128, "TriRecord is 128 B");
 // Texture coordinates of a face's three corners (compute.wgsl:218-220), 32 B.
 struct alignas(16) FaceUV {
     float uv0[2], uv1[2], uv2[2];
-    float pad[2];
+    uint32_t material;  // index into MaterialRec[] (multi-material scenes; 0 otherwise)
+    float pad;
 };
+
+// One material of a multi-material scene (extension: the reference binds materials[0] only,
+// triangle_list.rs:212): MaterialData's ambient / specular + its decoded diffuse texture.
+struct alignas(16) MaterialRec {
+    float ambient[3];  uint32_t tex_w;
+    float specular[3]; uint32_t tex_h;
+    const float4 *tex; uint64_t pad;
+};
+static_assert(sizeof(MaterialRec) == 48, "MaterialRec is 48 B");
 static_assert(sizeof(FaceUV) == 32, "FaceUV is 32 B");
 
 // The three corners again, packed (48 B): what the conservative tile/block
@@ -118,6 +128,10 @@ struct FrameParams {
     float sphere_rect[RWR_MAX_SPHERES][4];
     float ambient[4];
     float specular[4];
+    // multi-material scenes (n_materials > 1): per-face material through FaceUV::material
+    const MaterialRec *materials;
+    uint32_t n_materials;
+    uint32_t pad_m;
 };
 
 // context.cpp: records the calling thread's error message, returns `code`.
@@ -125,8 +139,8 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 
 // kernels_primary.hip
 hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, const rwr_model_face_small *faces,
-                          uint32_t n_faces, const rwr_instance_raw *instances, uint32_t n_instances,
-                          TriRecord *tris, FaceUV *face_uv, CullRec *cull);
+                          const uint32_t *face_material, uint32_t n_faces, const rwr_instance_raw *instances,
+                          uint32_t n_instances, TriRecord *tris, FaceUV *face_uv, CullRec *cull);
 // Wavefront integrator state (kernels_wavefront.hip).  Ray queue = SoA in HBM, 40 B per
 // bounce ray: q0 = {O.xyz, pixel}, q1 = {D.xyz, thr.r}, q2 = {thr.g, thr.b}; workgroup w of
 // the primary stage owns slots [256 w, 256 w + seg_count[w]).

@@ -134,8 +134,12 @@ RWR_DEV f3 shade_winner(const FrameParams &p, const PrimaryHit &r, const TriReco
         const TriRecord &T = tris[r.obj];
         f3 N = ld3(T.N);
         if (r.mesh.ndotd > 0.0f) N = neg3(N);  // compute.wgsl:140-142
-        return shade_mesh(face_uv[r.obj], r.mesh.u, r.mesh.v, T.denom, N, D, p.ambient, p.specular, tex, p.tex_w, p.tex_h,
-                          albedo);
+        const FaceUV &fuv = face_uv[r.obj];
+        if (p.n_materials > 1u) {  // wave-uniform: per-face material (extension)
+            const MaterialRec &M = p.materials[fuv.material];
+            return shade_mesh(fuv, r.mesh.u, r.mesh.v, T.denom, N, D, M.ambient, M.specular, M.tex, M.tex_w, M.tex_h, albedo);
+        }
+        return shade_mesh(fuv, r.mesh.u, r.mesh.v, T.denom, N, D, p.ambient, p.specular, tex, p.tex_w, p.tex_h, albedo);
     }
     const uint32_t k = (uint32_t)(-2 - r.obj);
     const f3 P = along(O, r.t, D);
