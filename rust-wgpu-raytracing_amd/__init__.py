@@ -17,7 +17,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librwr_hip.so")
+LIB_PATH = os.environ.get("RWR_HIP_LIB") or os.path.join(_HERE, "lib", "librwr_hip.so")  # override: A/B runs of two builds
 RES_DIR = os.path.join(_HERE, "res")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rwr_hip.h")
 

@@ -74,7 +74,7 @@ struct rwr_context {
     DeviceBuffer<rwr_model_face_small> d_faces;
     DeviceBuffer<rwr_instance_raw> d_instances;
     DeviceBuffer<TriRecord> d_tris;
-    DeviceBuffer<FaceUV> d_face_uv;
+    DeviceBuffer<ShadeRec> d_shade;
     DeviceBuffer<CullRec> d_cull;
     DeviceBuffer<FrameTri> d_ftris;
     DeviceBuffer<uint32_t> d_bin_lists, d_bin_counts;   // per-frame screen bins (large scenes)
@@ -257,11 +257,11 @@ int rebuild_tris(rwr_context *ctx)
     if (!ctx->tris_dirty) return RWR_OK;
     const uint32_t total = ctx->n_faces * (ctx->n_instances ? ctx->n_instances : 1u);
     RWR_HIP_CHECK(ctx->d_tris.ensure(total));
-    RWR_HIP_CHECK(ctx->d_face_uv.ensure(total));
+    RWR_HIP_CHECK(ctx->d_shade.ensure(total));
     RWR_HIP_CHECK(ctx->d_cull.ensure(total));
     RWR_HIP_CHECK(ctx->d_ftris.ensure(total));
     RWR_HIP_CHECK(launch_prebake(ctx->stream, ctx->d_verts.ptr, ctx->d_faces.ptr, ctx->d_face_mat.ptr, ctx->n_faces, ctx->d_instances.ptr,
-                                 ctx->n_instances, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_cull.ptr));
+                                 ctx->n_instances, ctx->d_materials.ptr, ctx->d_tris.ptr, ctx->d_shade.ptr, ctx->d_cull.ptr));
     // BVH for incoherent rays, built on the host from the device's own world-space corners
     // (so instancing arithmetic happens in exactly one place, k_prebake)
     std::vector<CullRec> host_cull(total);
@@ -344,7 +344,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
     DeviceGuard g(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
-    ctx->d_tris.release(); ctx->d_face_uv.release(); ctx->d_cull.release(); ctx->d_ftris.release(); ctx->d_bin_lists.release(); ctx->d_bin_counts.release();
+    ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release(); ctx->d_ftris.release(); ctx->d_bin_lists.release(); ctx->d_bin_counts.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
     ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_seg_count.release(); ctx->d_seg_total.release(); for (auto &t : ctx->d_texs) t.release();
     ctx->d_face_mat.release(); ctx->d_materials.release();
@@ -404,6 +404,8 @@ int rwr_scene_add_mesh(rwr_context *ctx, const rwr_model_vertex_small *verts, ui
         return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL mesh array with n_faces = %u", n_faces);
     if (n_verts == 0 || tex_w == 0 || tex_h == 0)
         return set_error(RWR_ERR_INVALID_ARGUMENT, "empty vertex array or texture with n_faces = %u", n_faces);
+    if (tex_w > kMaxTextureDim || tex_h > kMaxTextureDim)  // byte offsets of the taps are 32-bit (rwr_device.h)
+        return set_error(RWR_ERR_INVALID_ARGUMENT, "texture %ux%u larger than %ux%u", tex_w, tex_h, kMaxTextureDim, kMaxTextureDim);
     // The shader indexes vertice_list unchecked (compute.wgsl:191-193); an
     // out-of-range index would be a GPU fault here, so it is rejected up front.
     for (uint32_t f = 0; f < n_faces; f++)
@@ -443,6 +445,7 @@ int rwr_scene_add_mesh(rwr_context *ctx, const rwr_model_vertex_small *verts, ui
     MaterialRec M{};
     for (int k = 0; k < 3; k++) { M.ambient[k] = material->ambient[k]; M.specular[k] = material->specular[k]; }
     M.tex_w = tex_w; M.tex_h = tex_h; M.tex = tex.ptr;
+    M.wmax = (float)(tex_w - 1u); M.hmax = (float)(tex_h - 1u);
     ctx->st_materials.push_back(M);
     if (mid == 0) ctx->material = *material;
     return RWR_OK;
@@ -574,6 +577,8 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     fp.n_tris = ctx->n_tris;
     fp.tex_w = ctx->tex_w;
     fp.tex_h = ctx->tex_h;
+    fp.tex_wmax = ctx->tex_w ? (float)(ctx->tex_w - 1u) : 0.0f;
+    fp.tex_hmax = ctx->tex_h ? (float)(ctx->tex_h - 1u) : 0.0f;
     fp.flags = rp.flags;
     for (int k = 0; k < 3; k++) {
         fp.ambient[k] = ctx->material.ambient[k];
@@ -625,13 +630,13 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     if (time_this && !dispatch_timed) RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs], ctx->stream));
     if (!wavefront && (rp.flags & RWR_FLAG_USE_BVH)) {
         const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
-        RWR_HIP_CHECK(launch_primary_bvh(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, bvh_p, tex0, tg));
+        RWR_HIP_CHECK(launch_primary_bvh(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh_p, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront) {
         if ((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel)
-            RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, tex0, tg));
+            RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, ctx->d_ftris.ptr, tex0, tg));
         else
-            RWR_HIP_CHECK(launch_primary_p2(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, tex0, tg,
+            RWR_HIP_CHECK(launch_primary_p2(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, ctx->d_ftris.ptr, tex0, tg,
                                             dispatch_timed ? ctx->timing_events[2 * ctx->timing_pairs] : nullptr,
                                             dispatch_timed ? ctx->timing_events[2 * ctx->timing_pairs + 1] : nullptr));
         ctx->last_spp = 0;
@@ -651,10 +656,10 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
         for (uint32_t sidx = 0; sidx < rp.spp; sidx++) {
             fp.sample = sidx;
-            RWR_HIP_CHECK(launch_wf_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, ctx->d_ftris.ptr, tex0,
+            RWR_HIP_CHECK(launch_wf_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, ctx->d_ftris.ptr, tex0,
                                             tg, wf));
             if (rp.max_bounces)
-                RWR_HIP_CHECK(launch_wf_bounce(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_face_uv.ptr, bvh, tex0,
+                RWR_HIP_CHECK(launch_wf_bounce(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh, tex0,
                                                wf, n_segments));
         }
         RWR_HIP_CHECK(launch_wf_resolve(ctx->stream, fp, tg, wf));

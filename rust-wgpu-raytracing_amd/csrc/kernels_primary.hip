@@ -29,12 +29,12 @@ namespace rwr {
 
 // ---------------------------------------------------------------------------
 // Scene prebake: ModelVertexSmall[] + ModelFaceSmall[] (+ rigid instances)
-// -> TriRecord[] + FaceUV[].  One thread per (instance, face).
+// -> TriRecord[] + ShadeRec[] + CullRec[].  One thread per (instance, face).
 __global__ void __launch_bounds__(256)
 k_prebake(const rwr_model_vertex_small *__restrict__ verts, const rwr_model_face_small *__restrict__ faces,
           const uint32_t *__restrict__ face_material, uint32_t n_faces, const rwr_instance_raw *__restrict__ instances,
-          uint32_t n_instances,
-          TriRecord *__restrict__ tris, FaceUV *__restrict__ face_uv, CullRec *__restrict__ cull)
+          uint32_t n_instances, const MaterialRec *__restrict__ materials,
+          TriRecord *__restrict__ tris, ShadeRec *__restrict__ shade, CullRec *__restrict__ cull)
 {
     const uint32_t total = n_faces * (n_instances ? n_instances : 1u);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,13 +67,26 @@ k_prebake(const rwr_model_vertex_small *__restrict__ verts, const rwr_model_face
     T.e2[0] = e2.x; T.e2[1] = e2.y; T.e2[2] = e2.z; T.pad4 = 0.0f;
     T.pad5[0] = T.pad5[1] = T.pad5[2] = T.pad5[3] = 0.0f;
     tris[i] = T;
-    FaceUV U;
-    U.uv0[0] = v0.tex_coords[0]; U.uv0[1] = v0.tex_coords[1];
-    U.uv1[0] = v1.tex_coords[0]; U.uv1[1] = v1.tex_coords[1];
-    U.uv2[0] = v2.tex_coords[0]; U.uv2[1] = v2.tex_coords[1];
-    U.material = face_material ? face_material[f] : 0u;
-    U.pad = 0.0f;
-    face_uv[i] = U;
+    // Shading record (colour path): the face-only part of compute.wgsl:217-234 in double, rounded once.
+    // A degenerate face (N = 0) gets non-finite values and can never be hit (:94).
+    ShadeRec S;
+    const uint32_t mat = face_material ? face_material[f] : 0u;
+    const double tw = (double)materials[mat].tex_w, th = (double)materials[mat].tex_h;
+    const double den = (double)T.denom, inv_len = 1.0 / sqrt(den);
+    const double nx = N.x * inv_len, ny = N.y * inv_len, nz = N.z * inv_len;
+    const double inv_l = 1.0 / sqrt(27.0);  // -normalize(vec3(1, -1, -5)), :55
+    S.n[0] = (float)nx; S.n[1] = (float)ny; S.n[2] = (float)nz;
+    S.ndl0 = (float)((-nx + ny + 5.0 * nz) * inv_l);
+    // barycentric = (u, v, den - u - v) / den on (v0, v1, v2) (:144-147); texel x = tw * tex.x - 0.5,
+    // texel y = th * (1 - tex.y) - 0.5 (:224 and the sampler's half-texel offset)
+    const double u0 = v0.tex_coords[0], u1 = v1.tex_coords[0], u2 = v2.tex_coords[0];
+    const double w0 = v0.tex_coords[1], w1 = v1.tex_coords[1], w2 = v2.tex_coords[1];
+    S.c0[0] = (float)(tw * u2 - 0.5);         S.c0[1] = (float)(th * (1.0 - w2) - 0.5);
+    S.c1[0] = (float)(tw * (u0 - u2) / den);  S.c1[1] = (float)(-th * (w0 - w2) / den);
+    S.c2[0] = (float)(tw * (u1 - u2) / den);  S.c2[1] = (float)(-th * (w1 - w2) / den);
+    S.material = mat;
+    S.pad = 0.0f;
+    shade[i] = S;
     CullRec R;
     R.p0[0] = p0.x; R.p0[1] = p0.y; R.p0[2] = p0.z;
     R.p1[0] = p1.x; R.p1[1] = p1.y; R.p1[2] = p1.z;
@@ -84,12 +97,12 @@ k_prebake(const rwr_model_vertex_small *__restrict__ verts, const rwr_model_face
 
 hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, const rwr_model_face_small *faces,
                           const uint32_t *face_material, uint32_t n_faces, const rwr_instance_raw *instances,
-                          uint32_t n_instances, TriRecord *tris, FaceUV *face_uv, CullRec *cull)
+                          uint32_t n_instances, const MaterialRec *materials, TriRecord *tris, ShadeRec *shade, CullRec *cull)
 {
     const uint32_t total = n_faces * (n_instances ? n_instances : 1u);
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(k_prebake, dim3((total + 255) / 256), dim3(256), 0, s, verts, faces, face_material, n_faces,
-                       instances, n_instances, tris, face_uv, cull);
+                       instances, n_instances, materials, tris, shade, cull);
     return hipGetLastError();
 }
 
@@ -169,7 +182,7 @@ hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tri
 // ---------------------------------------------------------------------------
 template <bool AUX, bool CULL>
 __global__ void __launch_bounds__(256, 8)  // 8 waves per SIMD: <= 64 VGPRs
-k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
+k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
           const FrameTri *__restrict__ ftris, const float4 *__restrict__ tex,
           const Targets tg)
 {
@@ -193,7 +206,7 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV 
     // final_color with alpha 1 + 1 (compute.wgsl:231-234).
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
     if (r.obj != -1) {
-        const f3 c = shade_winner(p, r, tris, face_uv, tex, O, D, nullptr);
+        const f3 c = shade_winner(p, r.obj, r.t, r.mesh.u, r.mesh.v, r.mesh.ndotd, shade, tex, O, D).colour;
         cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
     }
 
@@ -210,7 +223,7 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV 
     }
 }
 
-hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                           const FrameTri *ftris, const float4 *tex, const Targets &tg)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
@@ -218,10 +231,10 @@ hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord 
     const dim3 block(256);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
     const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
-    if (aux && do_cull) hipLaunchKernelGGL((k_primary<true, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
-    else if (aux) hipLaunchKernelGGL((k_primary<true, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
-    else if (do_cull) hipLaunchKernelGGL((k_primary<false, true>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
-    else hipLaunchKernelGGL((k_primary<false, false>), grid, block, 0, s, fp, tris, face_uv, ftris, tex, tg);
+    if (aux && do_cull) hipLaunchKernelGGL((k_primary<true, true>), grid, block, 0, s, fp, tris, shade, ftris, tex, tg);
+    else if (aux) hipLaunchKernelGGL((k_primary<true, false>), grid, block, 0, s, fp, tris, shade, ftris, tex, tg);
+    else if (do_cull) hipLaunchKernelGGL((k_primary<false, true>), grid, block, 0, s, fp, tris, shade, ftris, tex, tg);
+    else hipLaunchKernelGGL((k_primary<false, false>), grid, block, 0, s, fp, tris, shade, ftris, tex, tg);
     return hipGetLastError();
 }
 

@@ -12,9 +12,67 @@
 
 namespace rwr {
 
+// Mesh shading (triangle_list/compute.wgsl:217-234; colour path, tolerance 1e-4, not bit-exact) of the
+// winners of both pixels of a lane: per-pixel record loads, dot products and texture taps
+// (rwr_device.h), then the pair-wide steps — half vector, x^32, the final multiply-adds — as
+// packed instructions.  obj < 0 (no mesh winner) shades face 0; the caller drops that result.
+template <bool MULTI>
+RWR_DEV void shade_mesh_pair(const FrameParams &p, const ShadeRec *__restrict__ shade, const float4 *__restrict__ tex,
+                             i2 obj, const MeshHit2 &best, v3 D, f2 &cr, f2 &cg, f2 &cb)
+{
+    const v3 h = sub3(splat3(mesh_light_dir()), D);          // :229, un-normalised
+    const f2 hh = fma2(h.z, h.z, fma2(h.y, h.y, h.x * h.x));
+    const f2 rh = f2{__builtin_amdgcn_rsqf(hh.x), __builtin_amdgcn_rsqf(hh.y)};
+    f2 ndl, hn, tr, tg, tb;
+    f2 kar = splat(p.ambient[0]), kag = splat(p.ambient[1]), kab = splat(p.ambient[2]);
+    f2 ksr = splat(p.specular[0]), ksg = splat(p.specular[1]), ksb = splat(p.specular[2]);
+    TexTaps taps[2];
+    const float4 *texk[2] = {tex, tex};
+    // phase 1, both pixels: record loads, light terms, tap addresses
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const ShadeRec &S = shade[(uint32_t)max(k ? obj.y : obj.x, 0)];
+        HalfVec hv;
+        hv.h = lane3(h, k);
+        hv.rh = k ? rh.y : rh.x;
+        float a, c;
+        mesh_light_terms(S, k ? best.ndotd.y : best.ndotd.x, hv, a, c);
+        if (k) { ndl.y = a; hn.y = c; } else { ndl.x = a; hn.x = c; }
+        const f2 pos = mesh_texel_pos(S, k ? best.u.y : best.u.x, k ? best.v.y : best.v.x);
+        if (MULTI) {  // per-face material (extension)
+            const MaterialRec &M = p.materials[S.material];
+            taps[k] = tex_taps(M.tex_w * 16u, M.wmax, M.hmax, pos);
+            texk[k] = M.tex;
+            if (k) { kar.y = M.ambient[0]; kag.y = M.ambient[1]; kab.y = M.ambient[2]; ksr.y = M.specular[0]; ksg.y = M.specular[1]; ksb.y = M.specular[2]; }
+            else { kar.x = M.ambient[0]; kag.x = M.ambient[1]; kab.x = M.ambient[2]; ksr.x = M.specular[0]; ksg.x = M.specular[1]; ksb.x = M.specular[2]; }
+        } else {
+            taps[k] = tex_taps(p.tex_w * 16u, p.tex_wmax, p.tex_hmax, pos);
+        }
+    }
+    // phase 2, one pixel after the other (the scheduling barriers keep 12, not 24, texel registers live)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const f3 t = tex_filter(texk[0], taps[0]);
+        tr.x = t.x; tg.x = t.y; tb.x = t.z;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const f3 t = tex_filter(texk[1], taps[1]);
+        tr.y = t.x; tg.y = t.y; tb.y = t.z;
+    }
+    f2 sp = hn * hn;  // pow(., 32) by five squarings (rwr_device.h pow32)
+    sp = sp * sp; sp = sp * sp; sp = sp * sp; sp = sp * sp;
+    cr = fma2(ksr, sp, fma2(tr, ndl, kar));                  // :231-233
+    cg = fma2(ksg, sp, fma2(tg, ndl, kag));
+    cb = fma2(ksb, sp, fma2(tb, ndl, kab));
+}
+
+#ifndef RWR_P2_OCC
+#define RWR_P2_OCC 7  // 72 VGPRs: the shading step needs 66; at 8 waves (64) it spills and is slower (measured)
+#endif
 template <bool AUX, bool CULL>
-__global__ void __launch_bounds__(256, 8)
-k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
+__global__ void __launch_bounds__(256, AUX ? 4 : RWR_P2_OCC)
+k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
              const FrameTri *__restrict__ ftris, const float4 *__restrict__ tex,
              const Targets tg)
 {
@@ -117,46 +175,67 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Face
         win_t = win ? best.t : win_t;
     }
 
-    // -- shade the winners and store --------------------------------------------
-    uint32_t rgba[2];
-    float4 cf[2];
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        PrimaryHit r;
-        r.depth_tex = k ? depth_tex.y : depth_tex.x;
-        r.obj = k ? obj.y : obj.x;
-        r.t = k ? win_t.y : win_t.x;
-        r.mesh.have = true;
-        r.mesh.t = r.t;
-        r.mesh.u = k ? best.u.y : best.u.x;
-        r.mesh.v = k ? best.v.y : best.v.x;
-        r.mesh.ndotd = k ? best.ndotd.y : best.ndotd.x;
-        r.mesh.idx = k ? best.idx.y : best.idx.x;
-        float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;  // untouched pixels keep the clear value
-        if (r.obj != -1) {
-            const f3 c = shade_winner(p, r, tris, face_uv, tex, O, lane3(D, k), nullptr);
-            cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
-        }
-        rgba[k] = pack_rgba8(cr, cg, cb, ca);
-        cf[k] = make_float4(cr, cg, cb, ca);
-    }
-
-    if (py < p.row_end && px0 < p.width) {
-        const size_t o = (size_t)py * p.width + px0;
-        const bool both = px0 + 1u < p.width;
-        const bool dbg = AUX && (p.flags & RWR_FLAG_DEBUG_COUNTS) != 0;
-        if (both && (o & 1u) == 0u) {  // 8-byte aligned pair (always, when the width is even)
-            *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(tg.color) + o) = make_uint2(rgba[0], rgba[1]);
+    // depth plane first (nothing below needs it): 8-byte aligned pair whenever the width is even
+    const bool in_frame = py < p.row_end && px0 < p.width;
+    const uint32_t o = py * p.width + px0;  // < 2^30 pixels (rwr_resize)
+    const bool both = px0 + 1u < p.width;
+    const bool pair_store = both && (o & 1u) == 0u;
+    if (in_frame) {
+        if (pair_store) {
             *reinterpret_cast<float2 *>(tg.depth + o) = make_float2(depth_tex.x, depth_tex.y);
         } else {
-            reinterpret_cast<uint32_t *>(tg.color)[o] = rgba[0];
             tg.depth[o] = depth_tex.x;
-            if (both) {
-                reinterpret_cast<uint32_t *>(tg.color)[o + 1] = rgba[1];
-                tg.depth[o + 1] = depth_tex.y;
+            if (both) tg.depth[o + 1] = depth_tex.y;
+        }
+    }
+
+    // -- shade the winners and store --------------------------------------------
+    // Sphere winners first (few tiles; one pixel at a time), straight to their packed form, so that the
+    // ray direction is dead before the mesh shading starts.  Untouched pixels keep the clear value.
+    uint32_t rgba[2] = {0u, 0u};
+    float4 cf[2];
+    if (AUX) cf[0] = cf[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (any2(obj < -1)) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int o = k ? obj.y : obj.x;
+            if (o < -1) {
+                const f3 Dk = lane3(D, k);
+                const f3 center = ld3(p.spheres[-2 - o].center);
+                float t = 0.0f;  // the winner's distance again (same function, same bits) rather than a live register pair
+                (void)sphere_ray_intersect_t(center, p.spheres[-2 - o].radius, O, Dk, t);
+                const f3 c = shade_sphere(cnormalize(sub3(along(O, t, Dk), center)), Dk);
+                rgba[k] = pack_rgba8(c.x, c.y, c.z, 2.0f);
+                if (AUX) cf[k] = make_float4(c.x, c.y, c.z, 2.0f);
             }
         }
+    }
+    if (__any(any2(obj >= 0))) {  // wave-uniform; lanes without a mesh winner shade face 0 and drop the result
+        f2 cr, cg, cb;
+        if (p.n_materials > 1u) shade_mesh_pair<true>(p, shade, tex, obj, best, D, cr, cg, cb);
+        else shade_mesh_pair<false>(p, shade, tex, obj, best, D, cr, cg, cb);
+        // rgba8unorm conversion of both pixels (rwr_device.h unorm8); alpha 2.0 -> 255
+        const f2 sr = fma2(cr, splat(255.0f), splat(0.5f)), sg = fma2(cg, splat(255.0f), splat(0.5f)),
+                 sb = fma2(cb, splat(255.0f), splat(0.5f));
+        const uint32_t m0 = unorm8_scaled(sr.x) | (unorm8_scaled(sg.x) << 8) | (unorm8_scaled(sb.x) << 16) | 0xff000000u;
+        const uint32_t m1 = unorm8_scaled(sr.y) | (unorm8_scaled(sg.y) << 8) | (unorm8_scaled(sb.y) << 16) | 0xff000000u;
+        rgba[0] = obj.x >= 0 ? m0 : rgba[0];
+        rgba[1] = obj.y >= 0 ? m1 : rgba[1];
         if (AUX) {
+            if (obj.x >= 0) cf[0] = make_float4(cr.x, cg.x, cb.x, 2.0f);
+            if (obj.y >= 0) cf[1] = make_float4(cr.y, cg.y, cb.y, 2.0f);
+        }
+    }
+
+    if (in_frame) {
+        if (pair_store) {
+            *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(tg.color) + o) = make_uint2(rgba[0], rgba[1]);
+        } else {
+            reinterpret_cast<uint32_t *>(tg.color)[o] = rgba[0];
+            if (both) reinterpret_cast<uint32_t *>(tg.color)[o + 1] = rgba[1];
+        }
+        if (AUX) {
+            const bool dbg = (p.flags & RWR_FLAG_DEBUG_COUNTS) != 0;
             reinterpret_cast<float4 *>(tg.color_f32)[o] = cf[0];
             tg.obj_id[o] = dbg ? (int32_t)dbg_listed : obj.x;
             tg.hit_t[o] = dbg ? (float)dbg_tested : win_t.x;
@@ -169,7 +248,7 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Face
     }
 }
 
-hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                              const FrameTri *ftris, const float4 *tex, const Targets &tg, hipEvent_t ev_start,
                              hipEvent_t ev_stop)
 {
@@ -180,10 +259,10 @@ hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriReco
     const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
     // ev_start / ev_stop (may be null): timestamps of this dispatch itself (hipExtLaunchKernelGGL), i.e. the
     // kernel's own duration as a profiler reports it, without the gap to the preceding kernel
-    if (aux && do_cull) hipExtLaunchKernelGGL((k_primary_p2<true, true>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, face_uv, ftris, tex, tg);
-    else if (aux) hipExtLaunchKernelGGL((k_primary_p2<true, false>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, face_uv, ftris, tex, tg);
-    else if (do_cull) hipExtLaunchKernelGGL((k_primary_p2<false, true>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, face_uv, ftris, tex, tg);
-    else hipExtLaunchKernelGGL((k_primary_p2<false, false>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, face_uv, ftris, tex, tg);
+    if (aux && do_cull) hipExtLaunchKernelGGL((k_primary_p2<true, true>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, shade, ftris, tex, tg);
+    else if (aux) hipExtLaunchKernelGGL((k_primary_p2<true, false>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, shade, ftris, tex, tg);
+    else if (do_cull) hipExtLaunchKernelGGL((k_primary_p2<false, true>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, shade, ftris, tex, tg);
+    else hipExtLaunchKernelGGL((k_primary_p2<false, false>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, shade, ftris, tex, tg);
     return hipGetLastError();
 }
 

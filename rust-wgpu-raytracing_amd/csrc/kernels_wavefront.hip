@@ -27,7 +27,7 @@ namespace rwr {
 
 template <bool AUX, bool CULL>
 __global__ void __launch_bounds__(256, 8)
-k_wf_primary(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
+k_wf_primary(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
              const FrameTri *__restrict__ ftris, const float4 *__restrict__ tex,
              const Targets tg, const WfBuffers wf)
 {
@@ -57,8 +57,9 @@ k_wf_primary(const FrameParams p, const TriRecord *__restrict__ tris, const Face
     float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     f3 albedo = mk3(0.0f, 0.0f, 0.0f);
     if (hit) {
-        const f3 c = shade_winner(p, r, tris, face_uv, tex, O, D, &albedo);
-        e0 = make_float4(c.x, c.y, c.z, 2.0f);
+        const Shaded sw = shade_winner(p, r.obj, r.t, r.mesh.u, r.mesh.v, r.mesh.ndotd, shade, tex, O, D);
+        albedo = sw.albedo;
+        e0 = make_float4(sw.colour.x, sw.colour.y, sw.colour.z, 2.0f);
     }
     if (in_range) {
         float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -118,7 +119,7 @@ k_wf_primary(const FrameParams p, const TriRecord *__restrict__ tris, const Face
 
 template <bool NODES_IN_LDS>
 __global__ void __launch_bounds__(256)
-k_wf_bounce(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
+k_wf_bounce(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
             const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -165,7 +166,7 @@ k_wf_bounce(const FrameParams p, const TriRecord *__restrict__ tris, const FaceU
 
     PrimaryHit r;
     r.depth_tex = 0.0f; r.obj = obj; r.t = best_t; r.mesh = mh;
-    const f3 e1 = shade_winner(p, r, tris, face_uv, tex, O, D, nullptr);
+    const f3 e1 = shade_winner(p, r.obj, r.t, r.mesh.u, r.mesh.v, r.mesh.ndotd, shade, tex, O, D).colour;
     float4 acc = wf.accum[pixel];
     acc.x += thr.x * e1.x; acc.y += thr.y * e1.y; acc.z += thr.z * e1.z;
     wf.accum[pixel] = acc;
@@ -179,7 +180,7 @@ k_wf_bounce(const FrameParams p, const TriRecord *__restrict__ tris, const FaceU
 // needs slowed EVERY frame 2.5x.
 template <bool AUX, bool NODES_IN_LDS>
 __global__ void __launch_bounds__(256)
-k_primary_bvh(const FrameParams p, const TriRecord *__restrict__ tris, const FaceUV *__restrict__ face_uv,
+k_primary_bvh(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
               const BvhDevice bvh, const float4 *__restrict__ tex, const Targets tg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -222,7 +223,7 @@ k_primary_bvh(const FrameParams p, const TriRecord *__restrict__ tris, const Fac
     }
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
     if (r.obj != -1) {
-        const f3 c = shade_winner(p, r, tris, face_uv, tex, O, D, nullptr);
+        const f3 c = shade_winner(p, r.obj, r.t, r.mesh.u, r.mesh.v, r.mesh.ndotd, shade, tex, O, D).colour;
         cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
     }
     if (in_range) {
@@ -237,7 +238,7 @@ k_primary_bvh(const FrameParams p, const TriRecord *__restrict__ tris, const Fac
     }
 }
 
-hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                               const BvhDevice &bvh, const float4 *tex, const Targets &tg)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
@@ -246,11 +247,11 @@ hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRec
     const size_t node_bytes = (size_t)bvh.n_nodes * sizeof(BvhNode4);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
     if (node_bytes + fixed <= 64u * 1024u) {
-        if (aux) hipLaunchKernelGGL((k_primary_bvh<true, true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, face_uv, bvh, tex, tg);
-        else hipLaunchKernelGGL((k_primary_bvh<false, true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, face_uv, bvh, tex, tg);
+        if (aux) hipLaunchKernelGGL((k_primary_bvh<true, true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, shade, bvh, tex, tg);
+        else hipLaunchKernelGGL((k_primary_bvh<false, true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, shade, bvh, tex, tg);
     } else {
-        if (aux) hipLaunchKernelGGL((k_primary_bvh<true, false>), grid, dim3(256), fixed, s, fp, tris, face_uv, bvh, tex, tg);
-        else hipLaunchKernelGGL((k_primary_bvh<false, false>), grid, dim3(256), fixed, s, fp, tris, face_uv, bvh, tex, tg);
+        if (aux) hipLaunchKernelGGL((k_primary_bvh<true, false>), grid, dim3(256), fixed, s, fp, tris, shade, bvh, tex, tg);
+        else hipLaunchKernelGGL((k_primary_bvh<false, false>), grid, dim3(256), fixed, s, fp, tris, shade, bvh, tex, tg);
     }
     return hipGetLastError();
 }
@@ -270,21 +271,21 @@ k_wf_resolve(const FrameParams p, const Targets tg, const WfBuffers wf)
     if (AUX) reinterpret_cast<float4 *>(tg.color_f32)[pixel] = make_float4(r, g, b, a);
 }
 
-hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                              const FrameTri *ftris, const float4 *tex, const Targets &tg,
                              const WfBuffers &wf)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
     const dim3 grid((fp.width + 31u) / 32u, (fp.row_end - fp.row_begin + 7u) / 8u);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0, do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
-    if (aux && do_cull) hipLaunchKernelGGL((k_wf_primary<true, true>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, tg, wf);
-    else if (aux) hipLaunchKernelGGL((k_wf_primary<true, false>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, tg, wf);
-    else if (do_cull) hipLaunchKernelGGL((k_wf_primary<false, true>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, tg, wf);
-    else hipLaunchKernelGGL((k_wf_primary<false, false>), grid, dim3(256), 0, s, fp, tris, face_uv, ftris, tex, tg, wf);
+    if (aux && do_cull) hipLaunchKernelGGL((k_wf_primary<true, true>), grid, dim3(256), 0, s, fp, tris, shade, ftris, tex, tg, wf);
+    else if (aux) hipLaunchKernelGGL((k_wf_primary<true, false>), grid, dim3(256), 0, s, fp, tris, shade, ftris, tex, tg, wf);
+    else if (do_cull) hipLaunchKernelGGL((k_wf_primary<false, true>), grid, dim3(256), 0, s, fp, tris, shade, ftris, tex, tg, wf);
+    else hipLaunchKernelGGL((k_wf_primary<false, false>), grid, dim3(256), 0, s, fp, tris, shade, ftris, tex, tg, wf);
     return hipGetLastError();
 }
 
-hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                             const BvhDevice &bvh, const float4 *tex, const WfBuffers &wf,
                             uint32_t n_segments)
 {
@@ -298,9 +299,9 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
     // 35 % SLOWER — 26.2 vs 19.7 ms at cfg3: a quarter of the waves, so less latency hiding and a
     // longer tail, for no gain in lane utilisation once finished rays are retired in groups.)
     if (node_bytes + fixed <= 64u * 1024u) {
-        hipLaunchKernelGGL((k_wf_bounce<true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, face_uv, bvh, tex, wf);
+        hipLaunchKernelGGL((k_wf_bounce<true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, shade, bvh, tex, wf);
     } else {
-        hipLaunchKernelGGL((k_wf_bounce<false>), grid, dim3(256), fixed, s, fp, tris, face_uv, bvh, tex, wf);
+        hipLaunchKernelGGL((k_wf_bounce<false>), grid, dim3(256), fixed, s, fp, tris, shade, bvh, tex, wf);
     }
     return hipGetLastError();
 }

@@ -21,6 +21,12 @@
 namespace rwr {
 
 struct f3 { float x, y, z; };
+// 2-wide vectors: clang's ext-vector operators apply the scalar operation to each element (one IEEE
+// rounding per operation, no contraction in this translation unit) and map to v_pk_*_f32.
+typedef float f2 __attribute__((ext_vector_type(2)));
+RWR_DEV f2 splat(float s) { return f2{s, s}; }
+RWR_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32: colour / culling code only
+RWR_DEV f2 ld2(const float *p) { return f2{p[0], p[1]}; }
 
 RWR_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 RWR_DEV f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
@@ -129,60 +135,111 @@ RWR_DEV f3 shade_sphere(f3 n, f3 D)
     return mk3(k * 1.0f + specular, k * 0.0f + specular, k * 0.0f + specular);
 }
 
+// -normalize(kLightDir) of the mesh shader, compute.wgsl:55 (folded at compile time).
+RWR_DEV f3 mesh_light_dir() { return neg3(normalize3(mk3(1.0f, -1.0f, -5.0f))); }
+
 // Rgba8UnormSrgb texel fetch + bilinear filter with ClampToEdge
-// (texture.rs:122,151-159; textureSampleGrad at LOD 0, compute.wgsl:225).
+// (texture.rs:122,151-159; textureSampleGrad at LOD 0, compute.wgsl:225) at texel-space
+// position fxy = (u * tex_w - 0.5, v * tex_h - 0.5).
 // `tex` holds the texels already decoded to linear f32 (one float4 per texel, made at
 // upload from the same 256-entry sRGB table the oracle uses): what the sampler
-// hardware does before filtering, done once instead of per tap.
-RWR_DEV f3 tex_sample_bilinear(const float4 *__restrict__ tex, uint32_t tw, uint32_t th, float u, float v)
+// hardware does before filtering, done once instead of per tap.  pitch = 16 * tex_w bytes
+// (< 2^24, checked at upload: row * pitch is a v_mul_u32_u24, + column * 16 a v_lshl_add_u32).
+// v_med3 returns a finite operand when fx / fy is NaN, so no tap can leave the texture.
+struct TexTaps { uint32_t o00, o10, o01, o11; f2 a; };  // byte offsets of the 2x2 footprint, fractional position
+RWR_DEV TexTaps tex_taps(uint32_t pitch, float wmax, float hmax, f2 fxy)
 {
-    float fx = u * (float)tw - 0.5f;
-    float fy = v * (float)th - 0.5f;
-    float x0f = floorf(fx), y0f = floorf(fy);
-    float ax = fx - x0f, ay = fy - y0f;
-    float wmax = (float)(tw - 1), hmax = (float)(th - 1);
-    uint32_t x0 = (uint32_t)fminf(fmaxf(x0f, 0.0f), wmax);
-    uint32_t x1 = (uint32_t)fminf(fmaxf(x0f + 1.0f, 0.0f), wmax);
-    uint32_t y0 = (uint32_t)fminf(fmaxf(y0f, 0.0f), hmax);
-    uint32_t y1 = (uint32_t)fminf(fmaxf(y0f + 1.0f, 0.0f), hmax);
-    const float4 t00 = tex[y0 * tw + x0], t10 = tex[y0 * tw + x1];
-    const float4 t01 = tex[y1 * tw + x0], t11 = tex[y1 * tw + x1];
-    float w00 = (1.0f - ax) * (1.0f - ay), w10 = ax * (1.0f - ay);
-    float w01 = (1.0f - ax) * ay, w11 = ax * ay;
-    return mk3(__builtin_fmaf(t11.x, w11, __builtin_fmaf(t01.x, w01, __builtin_fmaf(t10.x, w10, t00.x * w00))),
-               __builtin_fmaf(t11.y, w11, __builtin_fmaf(t01.y, w01, __builtin_fmaf(t10.y, w10, t00.y * w00))),
-               __builtin_fmaf(t11.z, w11, __builtin_fmaf(t01.z, w01, __builtin_fmaf(t10.z, w10, t00.z * w00))));
+    const f2 f0 = f2{floorf(fxy.x), floorf(fxy.y)};
+    const f2 f1 = f0 + 1.0f;
+    const uint32_t x0 = (uint32_t)__builtin_amdgcn_fmed3f(f0.x, 0.0f, wmax) << 4;
+    const uint32_t x1 = (uint32_t)__builtin_amdgcn_fmed3f(f1.x, 0.0f, wmax) << 4;
+    const uint32_t y0 = (uint32_t)__builtin_amdgcn_fmed3f(f0.y, 0.0f, hmax);
+    const uint32_t y1 = (uint32_t)__builtin_amdgcn_fmed3f(f1.y, 0.0f, hmax);
+    TexTaps t;
+    t.o00 = __umul24(y0, pitch) + x0; t.o10 = __umul24(y0, pitch) + x1;
+    t.o01 = __umul24(y1, pitch) + x0; t.o11 = __umul24(y1, pitch) + x1;
+    t.a = fxy - f0;
+    return t;
+}
+RWR_DEV f3 tex_filter(const float4 *__restrict__ tex, const TexTaps &t)
+{
+    const char *base = reinterpret_cast<const char *>(tex);
+    const float4 t00 = *reinterpret_cast<const float4 *>(base + t.o00);
+    const float4 t10 = *reinterpret_cast<const float4 *>(base + t.o10);
+    const float4 t01 = *reinterpret_cast<const float4 *>(base + t.o01);
+    const float4 t11 = *reinterpret_cast<const float4 *>(base + t.o11);
+    const f2 a = t.a, b = 1.0f - a;
+    const float w00 = b.x * b.y, w10 = a.x * b.y, w01 = b.x * a.y, w11 = a.x * a.y;
+    // (r, g) as a pair (adjacent in the loaded texel), b alone
+    const f2 rg = fma2(f2{t11.x, t11.y}, splat(w11), fma2(f2{t01.x, t01.y}, splat(w01),
+                  fma2(f2{t10.x, t10.y}, splat(w10), f2{t00.x, t00.y} * w00)));
+    const float bl = __builtin_fmaf(t11.z, w11, __builtin_fmaf(t01.z, w01, __builtin_fmaf(t10.z, w10, t00.z * w00)));
+    return mk3(rg.x, rg.y, bl);
+}
+RWR_DEV f3 tex_sample_bilinear(const float4 *__restrict__ tex, uint32_t pitch, float wmax, float hmax, f2 fxy)
+{
+    return tex_filter(tex, tex_taps(pitch, wmax, hmax, fxy));
 }
 
-// Mesh shading, triangle_list/compute.wgsl:217-234 (colour path: see the header).
-// (eu, ev) are the winner's un-normalised edge functions, denom = dot(N, N);
-// N_facing the face normal already flipped towards the ray (compute.wgsl:140-147).
-// *albedo receives the filtered texel.
-RWR_DEV f3 shade_mesh(const FaceUV &fuv, float eu, float ev, float denom, f3 N_facing, f3 D, const float *ka,
-                      const float *ks, const float4 *__restrict__ tex, uint32_t tw, uint32_t th, f3 *albedo)
+// Mesh shading, triangle_list/compute.wgsl:217-234 (colour path: see the header), in three steps
+// so that callers with two pixels per lane can run the middle one packed.
+//
+// View-dependent, surface-independent part of Blinn-Phong: h = L - D (un-normalised half vector,
+// :229) and 1 / |h|.
+struct HalfVec { f3 h; float rh; };
+RWR_DEV HalfVec mesh_half_vector(f3 D)
 {
-    const float rden = __builtin_amdgcn_rcpf(denom);
-    const float b0 = eu * rden, b1 = ev * rden, b2 = 1.0f - b0 - b1;   // barycentric (u, v, 1-u-v), :144-147
-    const f3 n = cnormalize(N_facing);
-    float tu = __builtin_fmaf(b2, fuv.uv2[0], __builtin_fmaf(b1, fuv.uv1[0], b0 * fuv.uv0[0]));
-    float tv = __builtin_fmaf(b2, fuv.uv2[1], __builtin_fmaf(b1, fuv.uv1[1], b0 * fuv.uv0[1]));
-    tv = 1.0f - tv;
-    f3 texel = tex_sample_bilinear(tex, tw, th, tu, tv);
-    if (albedo) *albedo = texel;
-    const f3 nl = neg3(normalize3(mk3(1.0f, -1.0f, -5.0f)));  // -normalize(kLightDir), :55 (folded at compile time)
-    float ndl = fmaxf(0.0f, cdot(n, nl));
-    f3 diffuse = scale3(texel, ndl);
-    f3 half_dir = cnormalize(sub3(nl, D));
-    float sp = pow32(fmaxf(0.0f, cdot(half_dir, n)));
-    return mk3((ka[0] + diffuse.x) + ks[0] * sp, (ka[1] + diffuse.y) + ks[1] * sp, (ka[2] + diffuse.z) + ks[2] * sp);
+    HalfVec hv;
+    hv.h = sub3(mesh_light_dir(), D);
+    hv.rh = __builtin_amdgcn_rsqf(cdot(hv.h, hv.h));
+    return hv;
+}
+// Lambert term max(0, n.L) (:227) and the Blinn-Phong base max(0, dot(half_dir, n)) (:230) for the normal
+// flipped towards the ray (N = -N when dot(N, D) > 0, :140-142): the flip is a sign flip of both dot
+// products, applied as an XOR with the sign bit of dot(N, D) (never +-0 for an accepted hit, :94).
+RWR_DEV void mesh_light_terms(const ShadeRec &S, float ndotd, const HalfVec &hv, float &ndl, float &hn)
+{
+    const uint32_t sb = __float_as_uint(ndotd) & 0x80000000u;
+    ndl = fmaxf(-__uint_as_float(__float_as_uint(S.ndl0) ^ sb), 0.0f);
+    const float c = cdot(hv.h, ld3(S.n)) * hv.rh;
+    hn = fmaxf(-__uint_as_float(__float_as_uint(c) ^ sb), 0.0f);
+}
+// Filtered diffuse texel at the hit: (eu, ev) are the winner's un-normalised edge functions
+// (:126,135); the barycentric division, the tex_coords interpolation, the v flip and the texel-space
+// scale (:144-147,218-225) are the affine map prebaked into the ShadeRec.
+RWR_DEV f2 mesh_texel_pos(const ShadeRec &S, float eu, float ev)
+{
+    return fma2(splat(ev), ld2(S.c2), fma2(splat(eu), ld2(S.c1), ld2(S.c0)));
+}
+RWR_DEV f3 mesh_texel(const ShadeRec &S, float eu, float ev, const float4 *__restrict__ tex, uint32_t pitch, float wmax,
+                      float hmax)
+{
+    return tex_sample_bilinear(tex, pitch, wmax, hmax, mesh_texel_pos(S, eu, ev));
+}
+// (ambient + texel * n.L) + specular * pow(., 32), :231-233
+RWR_DEV f3 mesh_combine(f3 texel, float ndl, float sp, const float *ka, const float *ks)
+{
+    return mk3(__builtin_fmaf(ks[0], sp, __builtin_fmaf(texel.x, ndl, ka[0])),
+               __builtin_fmaf(ks[1], sp, __builtin_fmaf(texel.y, ndl, ka[1])),
+               __builtin_fmaf(ks[2], sp, __builtin_fmaf(texel.z, ndl, ka[2])));
+}
+struct Shaded { f3 colour, albedo; };  // local shading E and the surface's diffuse reflectance
+RWR_DEV Shaded shade_mesh(const ShadeRec &S, float eu, float ev, float ndotd, f3 D, const float *ka, const float *ks,
+                          const float4 *__restrict__ tex, uint32_t pitch, float wmax, float hmax)
+{
+    float ndl, hn;
+    mesh_light_terms(S, ndotd, mesh_half_vector(D), ndl, hn);
+    Shaded r;
+    r.albedo = mesh_texel(S, eu, ev, tex, pitch, wmax, hmax);
+    r.colour = mesh_combine(r.albedo, ndl, pow32(hn), ka, ks);
+    return r;
 }
 
-// rgba8unorm store conversion: clamp, scale, round half up.
-RWR_DEV uint32_t unorm8(float c)
-{
-    const float cc = __builtin_amdgcn_fmed3f(c, 0.0f, 1.0f);  // clamp; a NaN gives 0 like fmin(fmax(c,0),1)
-    return (uint32_t)(cc * 255.0f + 0.5f);                   // >= 0, so truncation is floor
-}
+// rgba8unorm store conversion: clamp, scale, round half up.  The clamp is applied after the scale
+// (med3 of c * 255 + 0.5 against [0.5, 255.5] = the clamp of c against [0, 1] carried through the
+// monotonic map; a NaN gives 0 like fmin(fmax(c, 0), 1)).
+RWR_DEV uint32_t unorm8_scaled(float v) { return (uint32_t)__builtin_amdgcn_fmed3f(v, 0.5f, 255.5f); }
+RWR_DEV uint32_t unorm8(float c) { return unorm8_scaled(__builtin_fmaf(c, 255.0f, 0.5f)); }
 RWR_DEV uint32_t pack_rgba8(float r, float g, float b, float a)
 {
     return unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | (unorm8(a) << 24);

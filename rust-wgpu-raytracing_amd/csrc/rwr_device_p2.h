@@ -17,13 +17,11 @@
 
 namespace rwr {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
 typedef int i2 __attribute__((ext_vector_type(2)));        // comparison masks: -1 / 0 per element
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
 struct v3 { f2 x, y, z; };
 
-RWR_DEV f2 splat(float s) { return f2{s, s}; }
 RWR_DEV v3 splat3(f3 a) { return v3{splat(a.x), splat(a.y), splat(a.z)}; }
 RWR_DEV v3 sub3(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 // WGSL dot / cross, literal (cf. rwr_device.h)

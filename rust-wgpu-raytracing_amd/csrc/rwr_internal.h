@@ -37,22 +37,33 @@ struct alignas(16) TriRecord {
 };
 static_assert(sizeof(TriRecord) == 128, "TriRecord is 128 B");
 
-// Texture coordinates of a face's three corners (compute.wgsl:218-220), 32 B.
-struct alignas(16) FaceUV {
-    float uv0[2], uv1[2], uv2[2];
-    uint32_t material;  // index into MaterialRec[] (multi-material scenes; 0 otherwise)
+// Per-face shading record (colour path only; 48 B = three dwordx4), made by k_prebake.
+// Everything of triangle_list/compute.wgsl:217-234 that depends on the face alone is folded in
+// double precision and rounded once: the unit normal, its Lambert term against the fixed
+// directional light (:55), and the affine map from the winner's un-normalised edge functions
+// (u, v) (:126,135) to texel space,  (x, y) = c0 + u*c1 + v*c2  with  x = tex_w * dot(barycentric,
+// tex_coords.x) - 0.5  (:144-147,218-225), y likewise with the 1 - v flip of :224.  (x, y) pairs are
+// adjacent so that the map is two v_pk_fma_f32.
+struct alignas(16) ShadeRec {
+    float n[3];  float ndl0;        // N / |N| (as wound, not flipped), dot(n, -normalize(kLightDir))
+    float c0[2], c1[2];
+    float c2[2]; uint32_t material; // index into MaterialRec[]
     float pad;
 };
+static_assert(sizeof(ShadeRec) == 48, "ShadeRec is 48 B");
 
-// One material of a multi-material scene (extension: the reference binds materials[0] only,
-// triangle_list.rs:212): MaterialData's ambient / specular + its decoded diffuse texture.
+// Largest texture edge accepted (wgpu's own default limit is 8192): keeps tap byte offsets in 32 bits.
+constexpr uint32_t kMaxTextureDim = 16384;
+
+// One material (MaterialData's ambient / specular, triangle_list.rs:24-33) with its decoded diffuse
+// texture.  The reference binds materials[0] only (triangle_list.rs:212); more than one is an extension.
 struct alignas(16) MaterialRec {
     float ambient[3];  uint32_t tex_w;
     float specular[3]; uint32_t tex_h;
-    const float4 *tex; uint64_t pad;
+    const float4 *tex;
+    float wmax, hmax;               // (float)(tex_w - 1), (float)(tex_h - 1): the ClampToEdge bounds
 };
 static_assert(sizeof(MaterialRec) == 48, "MaterialRec is 48 B");
-static_assert(sizeof(FaceUV) == 32, "FaceUV is 32 B");
 
 // The three corners again, packed (48 B): what the conservative tile/block
 // frustum tests read, one record per lane, coalesced.
@@ -118,6 +129,7 @@ struct FrameParams {
     uint32_t n_spheres;
     uint32_t n_tris;
     uint32_t tex_w, tex_h;
+    float tex_wmax, tex_hmax;     // (float)(tex_w - 1), (float)(tex_h - 1) of material 0
     uint32_t flags;
     uint32_t wave_cull_min;   // run the per-wave (8x8 tile) cull only for block lists longer than this
     // wavefront integrator (extension): sample being traced, samples per pixel, RNG seed, bounces
@@ -128,7 +140,7 @@ struct FrameParams {
     float sphere_rect[RWR_MAX_SPHERES][4];
     float ambient[4];
     float specular[4];
-    // multi-material scenes (n_materials > 1): per-face material through FaceUV::material
+    // multi-material scenes (n_materials > 1): per-face material through ShadeRec::material
     const MaterialRec *materials;
     uint32_t n_materials;
     uint32_t pad_m;
@@ -140,7 +152,7 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 // kernels_primary.hip
 hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, const rwr_model_face_small *faces,
                           const uint32_t *face_material, uint32_t n_faces, const rwr_instance_raw *instances,
-                          uint32_t n_instances, TriRecord *tris, FaceUV *face_uv, CullRec *cull);
+                          uint32_t n_instances, const MaterialRec *materials, TriRecord *tris, ShadeRec *shade, CullRec *cull);
 // Wavefront integrator state (kernels_wavefront.hip).  Ray queue = SoA in HBM, 40 B per
 // bounce ray: q0 = {O.xyz, pixel}, q1 = {D.xyz, thr.r}, q2 = {thr.g, thr.b}; workgroup w of
 // the primary stage owns slots [256 w, 256 w + seg_count[w]).
@@ -159,23 +171,23 @@ struct BvhDevice {
     uint32_t stack_depth;  // 3 * tree depth + 2
 };
 
-hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                              const FrameTri *ftris, const float4 *tex, const Targets &tg, hipEvent_t ev_start = nullptr,
                              hipEvent_t ev_stop = nullptr);
-hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                              const FrameTri *ftris, const float4 *tex, const Targets &tg,
                              const WfBuffers &wf);
-hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                             const BvhDevice &bvh, const float4 *tex, const WfBuffers &wf,
                             uint32_t n_segments);
-hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                               const BvhDevice &bvh, const float4 *tex, const Targets &tg);
 hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf);
 
 hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const CullRec *cull, uint32_t n_tris, FrameTri *ftris);
 hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *lists,
                             uint32_t *counts, uint32_t bins_x, uint32_t bins_y, uint32_t cap);
-hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const FaceUV *face_uv,
+hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                           const FrameTri *ftris, const float4 *tex, const Targets &tg);
 
 }  // namespace rwr

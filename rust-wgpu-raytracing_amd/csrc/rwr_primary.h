@@ -125,27 +125,27 @@ RWR_DEV void primary_visibility(const FrameParams &p, const TriRecord *__restric
     }
 }
 
-// Local shading E of the winning surface (colour path) -> rgb; alpha is 2.0 on a hit.
-// *albedo (may be null) receives the surface's diffuse reflectance.
-RWR_DEV f3 shade_winner(const FrameParams &p, const PrimaryHit &r, const TriRecord *__restrict__ tris,
-                        const FaceUV *__restrict__ face_uv, const float4 *__restrict__ tex, f3 O, f3 D, f3 *albedo)
+// Local shading E of the winning surface (colour path) -> rgb (alpha is 2.0 on a hit), and its albedo.
+// (obj, t: the winner and its distance; u, v, ndotd: MeshHit fields of a mesh winner — by value, a
+// reference to the hit record keeps part of it in memory.)
+RWR_DEV Shaded shade_winner(const FrameParams &p, int32_t obj, float t, float u, float v, float ndotd,
+                            const ShadeRec *__restrict__ shade, const float4 *__restrict__ tex, f3 O, f3 D)
 {
-    if (r.obj >= 0) {
-        const TriRecord &T = tris[r.obj];
-        f3 N = ld3(T.N);
-        if (r.mesh.ndotd > 0.0f) N = neg3(N);  // compute.wgsl:140-142
-        const FaceUV &fuv = face_uv[r.obj];
+    if (obj >= 0) {
+        const ShadeRec &S = shade[obj];
         if (p.n_materials > 1u) {  // wave-uniform: per-face material (extension)
-            const MaterialRec &M = p.materials[fuv.material];
-            return shade_mesh(fuv, r.mesh.u, r.mesh.v, T.denom, N, D, M.ambient, M.specular, M.tex, M.tex_w, M.tex_h, albedo);
+            const MaterialRec &M = p.materials[S.material];
+            return shade_mesh(S, u, v, ndotd, D, M.ambient, M.specular, M.tex, M.tex_w * 16u, M.wmax, M.hmax);
         }
-        return shade_mesh(fuv, r.mesh.u, r.mesh.v, T.denom, N, D, p.ambient, p.specular, tex, p.tex_w, p.tex_h, albedo);
+        return shade_mesh(S, u, v, ndotd, D, p.ambient, p.specular, tex, p.tex_w * 16u, p.tex_wmax, p.tex_hmax);
     }
-    const uint32_t k = (uint32_t)(-2 - r.obj);
-    const f3 P = along(O, r.t, D);
+    const uint32_t k = (uint32_t)(-2 - obj);
+    const f3 P = along(O, t, D);
     const f3 n = cnormalize(sub3(P, ld3(p.spheres[k].center)));
-    if (albedo) *albedo = mk3(1.0f, 0.0f, 0.0f);
-    return shade_sphere(n, D);
+    Shaded s;
+    s.albedo = mk3(1.0f, 0.0f, 0.0f);
+    s.colour = shade_sphere(n, D);
+    return s;
 }
 
 }  // namespace rwr
