@@ -77,6 +77,8 @@ struct rwr_context {
     DeviceBuffer<ShadeRec> d_shade;
     DeviceBuffer<CullRec> d_cull;
     DeviceBuffer<FrameTri> d_ftris;
+    DeviceBuffer<float> d_tnum;              // per frame: plane-distance numerator per face
+    DeviceBuffer<float4> d_ray_colp, d_ray_row;  // per frame: ray tables (FrameParams::ray_colp / ray_row)
     DeviceBuffer<uint32_t> d_bin_lists, d_bin_counts;   // per-frame screen bins (large scenes)
     uint32_t bin_min_faces = 256;                       // tunable: RWR_BIN_MIN_FACES
     bool force_one_pixel = false;                       // debug: RWR_ONE_PIXEL_PER_LANE=1
@@ -260,6 +262,7 @@ int rebuild_tris(rwr_context *ctx)
     RWR_HIP_CHECK(ctx->d_shade.ensure(total));
     RWR_HIP_CHECK(ctx->d_cull.ensure(total));
     RWR_HIP_CHECK(ctx->d_ftris.ensure(total));
+    RWR_HIP_CHECK(ctx->d_tnum.ensure(total));
     RWR_HIP_CHECK(launch_prebake(ctx->stream, ctx->d_verts.ptr, ctx->d_faces.ptr, ctx->d_face_mat.ptr, ctx->n_faces, ctx->d_instances.ptr,
                                  ctx->n_instances, ctx->d_materials.ptr, ctx->d_tris.ptr, ctx->d_shade.ptr, ctx->d_cull.ptr));
     // BVH for incoherent rays, built on the host from the device's own world-space corners
@@ -344,7 +347,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
     DeviceGuard g(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
-    ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release(); ctx->d_ftris.release(); ctx->d_bin_lists.release(); ctx->d_bin_counts.release();
+    ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release(); ctx->d_ftris.release(); ctx->d_tnum.release(); ctx->d_ray_colp.release(); ctx->d_ray_row.release(); ctx->d_bin_lists.release(); ctx->d_bin_counts.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
     ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_seg_count.release(); ctx->d_seg_total.release(); for (auto &t : ctx->d_texs) t.release();
     ctx->d_face_mat.release(); ctx->d_materials.release();
@@ -595,13 +598,24 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     fp.spp = rp.spp;
     fp.seed = rp.seed;
     fp.bounces = rp.max_bounces;
+    {
+        // Per-frame records and tables (k_frame_setup): they depend on the camera, so they are rebuilt
+        // every frame, on the render stream just ahead of the render kernel.  (Running this small
+        // kernel on a side stream, double-buffered so that it overlaps the previous frame, was
+        // measured 4-10 us SLOWER per frame than the 3 us it hides: cross-stream event waits cost
+        // more than the kernel.)
+        FrameSetupOut so{};
+        so.ray_pairs = ((ctx->screen.width + 63u) / 64u) * 32u;  // whole 64-pixel workgroup columns
+        so.ray_rows = ctx->screen.height + 8u;                   // whole 8-row tiles below any band
+        RWR_HIP_CHECK(ctx->d_ray_colp.ensure(2u * (size_t)so.ray_pairs));
+        RWR_HIP_CHECK(ctx->d_ray_row.ensure(so.ray_rows));
+        so.ftris = ctx->d_ftris.ptr; so.tnum = ctx->d_tnum.ptr;
+        so.ray_colp = ctx->d_ray_colp.ptr; so.ray_row = ctx->d_ray_row.ptr;
+        RWR_HIP_CHECK(launch_frame_setup(ctx->stream, cc, *camera, ctx->screen.width, ctx->screen.height, ctx->d_cull.ptr,
+                                         ctx->d_tris.ptr, ctx->n_tris, so));
+        fp.ray_colp = so.ray_colp; fp.ray_row = so.ray_row; fp.tnum = so.tnum;
+    }
     if (ctx->n_tris && !(rp.flags & RWR_FLAG_NO_CULL)) {
-        // Per-frame, per-face culling records: they depend on the camera, so they are rebuilt
-        // every frame, on the render stream just ahead of the render kernel.  (Running this
-        // one-workgroup kernel on a side stream, double-buffered so that it overlaps the
-        // previous frame, was measured 4-10 us SLOWER per frame than the 3 us it hides:
-        // cross-stream event waits cost more than the kernel.)
-        RWR_HIP_CHECK(launch_frame_setup(ctx->stream, cc, ctx->d_cull.ptr, ctx->n_tris, ctx->d_ftris.ptr));
         const uint32_t bins_x = (ctx->screen.width + kBinW - 1) / kBinW, bins_y = (row_end - row_begin + kBinH - 1) / kBinH;
         // bin lists are worst-case sized (every face in every bin); beyond 2 GiB fall back to the un-binned walk
         const bool bins_fit = (uint64_t)bins_x * bins_y * ctx->n_tris * sizeof(uint32_t) <= (2ull << 30);

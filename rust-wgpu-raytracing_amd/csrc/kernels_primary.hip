@@ -107,12 +107,33 @@ hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, co
 }
 
 // ---------------------------------------------------------------------------
-// Per-frame culling records: one thread per face (rwr_cull.h).
+// Per-frame setup, one launch: blocks [0, nb_tris) make one face each per thread (the culling record
+// of rwr_cull.h and the ray-independent numerator of the plane distance), the blocks after them fill
+// the ray tables (FrameParams::ray_colp / ray_row), one column pair or one row per thread.
 __global__ void __launch_bounds__(256)
-k_frame_setup(const CullConsts cc, const CullRec *__restrict__ cull, uint32_t n_tris, FrameTri *__restrict__ ftris)
+k_frame_setup(const CullConsts cc, const rwr_camera_inv_uniform cam, uint32_t width, uint32_t height,
+              const CullRec *__restrict__ cull, const TriRecord *__restrict__ tris, uint32_t n_tris, uint32_t nb_tris,
+              const FrameSetupOut out)
 {
+    if (blockIdx.x >= nb_tris) {
+        const uint32_t e = (blockIdx.x - nb_tris) * blockDim.x + threadIdx.x;
+        const float(&p)[4][4] = cam.proj_inv;
+        if (e < out.ray_pairs) {
+            // compute.wgsl:151-152 for columns 2e and 2e + 1 (pixel centre: + 0.5), then the first term of :155
+            const float xa = 2.0f * ((float)(2u * e) + 0.5f) / (float)width - 1.0f;
+            const float xb = 2.0f * ((float)(2u * e + 1u) + 0.5f) / (float)width - 1.0f;
+            out.ray_colp[2u * e] = make_float4(p[0][0] * xa, p[0][0] * xb, p[0][1] * xa, p[0][1] * xb);
+            out.ray_colp[2u * e + 1u] = make_float4(p[0][2] * xa, p[0][2] * xb, xa, xb);
+        } else if (e - out.ray_pairs < out.ray_rows) {
+            const uint32_t y = e - out.ray_pairs;
+            const float ya = 2.0f * ((float)y + 0.5f) / (float)height - 1.0f;
+            out.ray_row[y] = make_float4(p[1][0] * ya, p[1][1] * ya, p[1][2] * ya, ya);
+        }
+        return;
+    }
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tris) return;
+    out.tnum[i] = -(dot3(ld3(tris[i].N), ld3(cam.origin)) + tris[i].d);  // compute.wgsl:99-102
     FrameTri T;
     if (cc.enabled) {
         T = make_frame_tri(cc, cull[i]);
@@ -124,13 +145,17 @@ k_frame_setup(const CullConsts cc, const CullRec *__restrict__ cull, uint32_t n_
         T.ey[0] = T.ey[1] = T.ey[2] = 0.0f;
         T.me0 = T.me1 = T.me2 = 0.0f;
     }
-    ftris[i] = T;
+    out.ftris[i] = T;
 }
 
-hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const CullRec *cull, uint32_t n_tris, FrameTri *ftris)
+hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const rwr_camera_inv_uniform &cam, uint32_t width,
+                              uint32_t height, const CullRec *cull, const TriRecord *tris, uint32_t n_tris,
+                              const FrameSetupOut &out)
 {
-    if (n_tris == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_frame_setup, dim3((n_tris + 255) / 256), dim3(256), 0, s, cc, cull, n_tris, ftris);
+    const uint32_t nb_tris = (n_tris + 255u) / 256u, nb_tab = (out.ray_pairs + out.ray_rows + 255u) / 256u;
+    if (nb_tris + nb_tab == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_frame_setup, dim3(nb_tris + nb_tab), dim3(256), 0, s, cc, cam, width, height, cull, tris, n_tris,
+                       nb_tris, out);
     return hipGetLastError();
 }
 

@@ -16,9 +16,13 @@ namespace rwr {
 // winners of both pixels of a lane: per-pixel record loads, dot products and texture taps
 // (rwr_device.h), then the pair-wide steps — half vector, x^32, the final multiply-adds — as
 // packed instructions.  obj < 0 (no mesh winner) shades face 0; the caller drops that result.
-template <bool MULTI>
+// UNIFORM: the wave ran the exact test on exactly one face (most tiles), so every mesh winner is that
+// face; its record `uS` was fetched by scalar loads together with the TriRecord, which takes one
+// dependent memory round trip (and six vector loads) out of the tile's critical path — at 1080p the
+// frame kernel spends as long on the latency chain of its first and last waves as on arithmetic.
+template <bool MULTI, bool UNIFORM>
 RWR_DEV void shade_mesh_pair(const FrameParams &p, const ShadeRec *__restrict__ shade, const float4 *__restrict__ tex,
-                             i2 obj, const MeshHit2 &best, v3 D, f2 &cr, f2 &cg, f2 &cb)
+                             i2 obj, const ShadeRec &uS, const MeshHit2 &best, v3 D, f2 &cr, f2 &cg, f2 &cb)
 {
     const v3 h = sub3(splat3(mesh_light_dir()), D);          // :229, un-normalised
     const f2 hh = fma2(h.z, h.z, fma2(h.y, h.y, h.x * h.x));
@@ -31,7 +35,7 @@ RWR_DEV void shade_mesh_pair(const FrameParams &p, const ShadeRec *__restrict__ 
     // phase 1, both pixels: record loads, light terms, tap addresses
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const ShadeRec &S = shade[(uint32_t)max(k ? obj.y : obj.x, 0)];
+        const ShadeRec &S = UNIFORM ? uS : shade[(uint32_t)max(k ? obj.y : obj.x, 0)];
         HalfVec hv;
         hv.h = lane3(h, k);
         hv.rh = k ? rh.y : rh.x;
@@ -76,16 +80,29 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Shad
              const FrameTri *__restrict__ ftris, const float4 *__restrict__ tex,
              const Targets tg)
 {
-    __shared__ PrimaryShared sh;
-
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t blk_x0 = blockIdx.x * 64u;
     const uint32_t tile_x0 = blk_x0 + wave * 16u;
     const uint32_t tile_y0 = p.row_begin + blockIdx.y * 8u;
     const uint32_t px0 = tile_x0 + 2u * (lane & 7u), py = tile_y0 + (lane >> 3);
 
+    // -- candidate faces of this wave's tile: the first 64 culling records are requested before anything
+    // else, so that their latency hides behind the ray generation ------------------------------
+    uint32_t n_src = p.n_tris;
+    const uint32_t *__restrict__ src = nullptr;
+    if (CULL && p.bins.enabled) {
+        const uint32_t bin = ((tile_y0 - p.row_begin) / kBinH) * p.bins.bins_x + blk_x0 / kBinW;
+        n_src = p.bins.counts[bin];
+        src = p.bins.lists + (size_t)bin * p.bins.cap;
+    }
+    n_src = __builtin_amdgcn_readfirstlane(n_src);
+    bool valid = lane < n_src;
+    uint32_t face = (valid && src) ? src[lane] : lane;
+    FrameTri cur;
+    if (CULL && valid) cur = ftris[face];
+
     const f3 O = ld3(p.cam.origin);
-    const v3 D = pixel_pair_ray_dir(p.cam, px0, py, p.width, p.height);
+    const v3 D = pixel_pair_ray_dir_tab(p.cam, p.ray_colp, p.ray_row, px0, py);
 
     // framebuffer state of the two pixels, as the reference's cleared textures hold it
     f2 depth_tex = splat(0.0f), win_t = splat(0.0f);
@@ -115,60 +132,40 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Shad
     best.t = best.u = best.v = best.ndotd = splat(0.0f);
     best.idx = u2{0u, 0u};
     uint32_t dbg_listed = 0, dbg_tested = 0;
-    if (p.n_tris) {
-        const float bx0 = (float)blk_x0;
-        const TileRect blk_rect = {bx0, ty0, bx0 + 64.0f, ty0 + 8.0f};
+    uint32_t n_tested = 0;  // wave-uniform
+    ShadeRec last_shade = {};  // of the face tested last (scalar registers)
+    {
+        // Each wave culls for its own 16x8 tile, 64 faces at a time, one per lane (rwr_cull.h), and walks
+        // the survivors in ascending face order: no LDS, no barrier.  The next 64 records are requested
+        // before the exact tests of the current ones.
         const TileRect tile_rect = {tx0, ty0, tx0 + 16.0f, ty0 + 8.0f};
-        uint32_t n_src = p.n_tris;
-        const uint32_t *__restrict__ src = nullptr;
-        if (CULL && p.bins.enabled) {
-            const uint32_t bin = ((tile_y0 - p.row_begin) / kBinH) * p.bins.bins_x + blk_x0 / kBinW;
-            n_src = p.bins.counts[bin];
-            src = p.bins.lists + (size_t)bin * p.bins.cap;
-        }
-        n_src = __builtin_amdgcn_readfirstlane(n_src);
-        for (uint32_t base = 0; base < n_src; base += 256u) {
-            // level 1: 256 faces vs the block rectangle, order-preserving compaction into LDS
-            const uint32_t e0 = base + threadIdx.x;
-            bool keep = e0 < n_src;
-            const uint32_t j = (keep && src) ? src[e0] : e0;
-            if (CULL && keep) keep = !rect_culls(ftris[j], blk_rect);
-            const unsigned long long m = __ballot(keep);
-            if (lane == 0) sh.wave_cnt[wave] = (uint32_t)__popcll(m);
-            __syncthreads();
-            uint32_t off = 0, total = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < 4; w++) {
-                const uint32_t c = sh.wave_cnt[w];
-                off += (w < wave) ? c : 0u;
-                total += c;
+        for (uint32_t base = 0; base < n_src; base += 64u) {
+            bool keep = valid;
+            if (CULL && keep) keep = !rect_culls(cur, tile_rect);
+            unsigned long long m = __ballot(keep);
+            const uint32_t my_face = face;
+            const uint32_t e = base + 64u + lane;
+            valid = e < n_src;
+            face = (valid && src) ? src[e] : e;
+            if (CULL && valid) cur = ftris[face];
+            if (AUX) dbg_listed += (uint32_t)__popcll(m);
+            while (m) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                // wave-uniform face index: the record comes in through scalar loads
+                const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_face, (int)b);
+                intersect_and_select(tris[idx], p.tnum[idx], idx, O, D, best);
+                n_tested++;
+                last_shade = shade[idx];
+                if (AUX) dbg_tested++;
             }
-            total = __builtin_amdgcn_readfirstlane(total);
-            if (AUX) dbg_listed += total;
-            if (keep) sh.cand[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
-            __syncthreads();
-            // level 2: list entries vs this wave's tile rectangle, then the exact test on both pixels
-            const bool wave_cull = CULL && total > p.wave_cull_min;
-            for (uint32_t cbase = 0; cbase < total; cbase += 64u) {
-                const uint32_t e = cbase + lane;
-                bool keep2 = e < total;
-                const uint32_t my_idx = keep2 ? sh.cand[e] : 0u;
-                if (wave_cull && keep2) keep2 = !rect_culls(ftris[my_idx], tile_rect);
-                unsigned long long m2 = __ballot(keep2);
-                while (m2) {
-                    const uint32_t b = (uint32_t)__builtin_ctzll(m2);
-                    m2 &= m2 - 1ull;
-                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_idx, (int)b);  // wave-uniform
-                    intersect_and_select(tris[idx], idx, O, D, best);
-                    if (AUX) dbg_tested++;
-                }
-            }
-            if (base + 256u < n_src) __syncthreads();
         }
     }
     if (any2(best.have)) {
         const f2 current_depth = 1.0f - depth_tex;  // compute.wgsl:210
-        const f2 depth = to_non_linear_depth(best.t);
+        // same bits either way; the short form covers every distance a scene produces (rwr_device.h)
+        const bool fast = !__any(any2(best.have & ~depth_fast_domain(best.t)));
+        const f2 depth = fast ? to_non_linear_depth_fast(best.t) : to_non_linear_depth(best.t);
         const i2 win = best.have & ~(depth >= current_depth);
         depth_tex = win ? (1.0f - depth) : depth_tex;
         obj = win ? i2{(int)best.idx.x, (int)best.idx.y} : obj;
@@ -182,7 +179,9 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Shad
     const bool pair_store = both && (o & 1u) == 0u;
     if (in_frame) {
         if (pair_store) {
-            *reinterpret_cast<float2 *>(tg.depth + o) = make_float2(depth_tex.x, depth_tex.y);
+            // streaming stores: the targets are written once and not read by this kernel; they must not
+            // push the texture and the face records out of the L2
+            __builtin_nontemporal_store(depth_tex, reinterpret_cast<f2 *>(tg.depth + o));
         } else {
             tg.depth[o] = depth_tex.x;
             if (both) tg.depth[o + 1] = depth_tex.y;
@@ -212,8 +211,9 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Shad
     }
     if (__any(any2(obj >= 0))) {  // wave-uniform; lanes without a mesh winner shade face 0 and drop the result
         f2 cr, cg, cb;
-        if (p.n_materials > 1u) shade_mesh_pair<true>(p, shade, tex, obj, best, D, cr, cg, cb);
-        else shade_mesh_pair<false>(p, shade, tex, obj, best, D, cr, cg, cb);
+        if (p.n_materials > 1u) shade_mesh_pair<true, false>(p, shade, tex, obj, last_shade, best, D, cr, cg, cb);
+        else if (n_tested == 1u) shade_mesh_pair<false, true>(p, shade, tex, obj, last_shade, best, D, cr, cg, cb);
+        else shade_mesh_pair<false, false>(p, shade, tex, obj, last_shade, best, D, cr, cg, cb);
         // rgba8unorm conversion of both pixels (rwr_device.h unorm8); alpha 2.0 -> 255
         const f2 sr = fma2(cr, splat(255.0f), splat(0.5f)), sg = fma2(cg, splat(255.0f), splat(0.5f)),
                  sb = fma2(cb, splat(255.0f), splat(0.5f));
@@ -229,7 +229,7 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Shad
 
     if (in_frame) {
         if (pair_store) {
-            *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(tg.color) + o) = make_uint2(rgba[0], rgba[1]);
+            __builtin_nontemporal_store(u2{rgba[0], rgba[1]}, reinterpret_cast<u2 *>(reinterpret_cast<uint32_t *>(tg.color) + o));
         } else {
             reinterpret_cast<uint32_t *>(tg.color)[o] = rgba[0];
             if (both) reinterpret_cast<uint32_t *>(tg.color)[o + 1] = rgba[1];

@@ -39,10 +39,43 @@ RWR_DEV v3 normalize3(v3 a)
     return v3{a.x / len, a.y / len, a.z / len};
 }
 
+// element-wise normalize3_fast / normalize_fast_domain (rwr_device.h)
+RWR_DEV bool normalize_fast_domain(v3 a)
+{
+    return normalize_fast_domain(mk3(a.x.x, a.y.x, a.z.x)) && normalize_fast_domain(mk3(a.x.y, a.y.y, a.z.y));
+}
+RWR_DEV f2 div_shared_rcp(f2 n, f2 d, f2 r)
+{
+    const f2 q0 = n * r;
+    const f2 q1 = fma2(fma2(-d, q0, n), r, q0);
+    return fma2(fma2(-d, q1, n), r, q1);
+}
+RWR_DEV v3 normalize3_fast(v3 a)
+{
+    const f2 len = sqrt2(dot3(a, a));
+    f2 r = f2{__builtin_amdgcn_rcpf(len.x), __builtin_amdgcn_rcpf(len.y)};
+    r = fma2(fma2(-len, r, splat(1.0f)), r, r);
+    return v3{div_shared_rcp(a.x, len, r), div_shared_rcp(a.y, len, r), div_shared_rcp(a.z, len, r)};
+}
+
 // compute.wgsl:78-80
 RWR_DEV f2 to_non_linear_depth(f2 depth)
 {
     return ((1.0f / depth) - (1.0f / kNear)) / ((1.0f / kFar) - (1.0f / kNear));
+}
+
+RWR_DEV i2 depth_fast_domain(f2 depth)
+{
+    return i2{depth_fast_domain(depth.x) ? -1 : 0, depth_fast_domain(depth.y) ? -1 : 0};
+}
+// element-wise to_non_linear_depth_fast (same operations per element, packed)
+RWR_DEV f2 to_non_linear_depth_fast(f2 depth)
+{
+    f2 r = f2{__builtin_amdgcn_rcpf(depth.x), __builtin_amdgcn_rcpf(depth.y)};
+    r = fma2(fma2(-depth, r, splat(1.0f)), r, r);
+    const f2 x = r - (1.0f / kNear);
+    const f2 q = x * kDepthRC;
+    return fma2(fma2(splat(-kDepthC), q, x), splat(kDepthRC), q);
 }
 
 // pixelToRay (compute.wgsl:150-164) for pixels (x0, y) and (x0 + 1, y), jitter (0.5, 0.5).
@@ -63,6 +96,30 @@ RWR_DEV v3 pixel_pair_ray_dir(const rwr_camera_inv_uniform &cam, uint32_t x0, ui
     w.x = m[0][0] * vx + m[1][0] * vy + m[2][0] * vz + m[3][0] * vw;
     w.y = m[0][1] * vx + m[1][1] * vy + m[2][1] * vz + m[3][1] * vw;
     w.z = m[0][2] * vx + m[1][2] * vy + m[2][2] * vz + m[3][2] * vw;
+    return normalize3(w);
+}
+
+// The same ray from the per-frame tables of k_frame_setup (FrameParams::ray_colp / ray_row; x0 even):
+// the table entries are the products proj_inv[0] * x_nds and proj_inv[1] * y_nds, so each sum below is
+// the shader's  m[0]*v.x + m[1]*v.y + m[2]*v.z + m[3]*v.w  with its first two products already rounded.
+RWR_DEV v3 pixel_pair_ray_dir_tab(const rwr_camera_inv_uniform &cam, const float4 *__restrict__ colp,
+                                  const float4 *__restrict__ row, uint32_t x0, uint32_t y)
+{
+    const float4 ca = colp[x0], cb = colp[x0 + 1u];   // entry pair of column pair x0 / 2
+    const float4 r = row[y];
+    const float(&p)[4][4] = cam.proj_inv;
+    const f2 vx = f2{ca.x, ca.y} + r.x + p[2][0] * 1.0f + p[3][0] * 1.0f;
+    const f2 vy = f2{ca.z, ca.w} + r.y + p[2][1] * 1.0f + p[3][1] * 1.0f;
+    const f2 vz = f2{cb.x, cb.y} + r.z + p[2][2] * 1.0f + p[3][2] * 1.0f;
+    const f2 vw = splat(0.0f);
+    const float(&m)[4][4] = cam.viewmodel_inv;
+    v3 w;
+    w.x = m[0][0] * vx + m[1][0] * vy + m[2][0] * vz + m[3][0] * vw;
+    w.y = m[0][1] * vx + m[1][1] * vy + m[2][1] * vz + m[3][1] * vw;
+    w.z = m[0][2] * vx + m[1][2] * vy + m[2][2] * vz + m[3][2] * vw;
+    // same bits either way (rwr_device.h normalize3_fast); a wave with an axis-parallel or absurdly
+    // scaled ray takes the compiler's division
+    if (__all(normalize_fast_domain(w))) return normalize3_fast(w);
     return normalize3(w);
 }
 
@@ -94,13 +151,14 @@ struct MeshHit2 {
 
 // triangleRayIntersect + selection (compute.wgsl:82-148, 198-201), branch-free, for a pixel pair
 // against a wave-uniform record (cf. intersect_and_select).
-RWR_DEV void intersect_and_select(const TriRecord &T, uint32_t idx, f3 O, v3 D, MeshHit2 &best)
+// tnum = -(dot(N, O) + d), the ray-independent numerator of :99-102 (k_frame_setup).
+RWR_DEV void intersect_and_select(const TriRecord &T, float tnum, uint32_t idx, f3 O, v3 D, MeshHit2 &best)
 {
     const f3 N1 = ld3(T.N);
     const v3 N = splat3(N1);
     const f2 ndotd = dot3(N, D);
     i2 hit = ~(abs2(ndotd) < kEpsilon);                       // :94
-    const f2 t = -(dot3(N1, O) + T.d) / ndotd;                // :99-102 (numerator is ray-independent here)
+    const f2 t = tnum / ndotd;                                // :99-102
     hit &= ~(t < 0.0f);                                       // :105
     const v3 P = along(splat3(O), t, D);                      // :110
     v3 C = cross3(splat3(ld3(T.e0)), sub3(P, splat3(ld3(T.p0))));

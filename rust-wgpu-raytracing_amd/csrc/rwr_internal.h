@@ -140,6 +140,16 @@ struct FrameParams {
     float sphere_rect[RWR_MAX_SPHERES][4];
     float ambient[4];
     float specular[4];
+    // Per-frame tables written by k_frame_setup (the frame kernel with centre rays reads them; nothing
+    // here changes a bit of the ray: the entries are the shader's own operations, hoisted because they
+    // depend on the column, the row or the face alone):
+    //   ray_colp[x / 2] (x even) = two float4 {c(x).x, c(x+1).x, c(x).y, c(x+1).y}, {c(x).z, c(x+1).z, -, -}
+    //   with c(x) = proj_inv[0].xyz * x_nds(x),  x_nds = 2 * (x + 0.5) / width - 1     (compute.wgsl:151-155)
+    //   ray_row[y] = {proj_inv[1].xyz * y_nds(y), y_nds}
+    //   tnum[face] = -(dot(N, origin) + d)                                              (compute.wgsl:99-102)
+    const float4 *ray_colp;
+    const float4 *ray_row;
+    const float *tnum;
     // multi-material scenes (n_materials > 1): per-face material through ShadeRec::material
     const MaterialRec *materials;
     uint32_t n_materials;
@@ -184,7 +194,17 @@ hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRec
                               const BvhDevice &bvh, const float4 *tex, const Targets &tg);
 hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf);
 
-hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const CullRec *cull, uint32_t n_tris, FrameTri *ftris);
+// per-frame records and tables (kernels_primary.hip): FrameTri + tnum per face, ray tables per column pair / row
+struct FrameSetupOut {
+    FrameTri *ftris;   // n_tris
+    float *tnum;       // n_tris
+    float4 *ray_colp;  // 2 * ray_pairs
+    float4 *ray_row;   // ray_rows
+    uint32_t ray_pairs, ray_rows;
+};
+hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const rwr_camera_inv_uniform &cam, uint32_t width,
+                              uint32_t height, const CullRec *cull, const TriRecord *tris, uint32_t n_tris,
+                              const FrameSetupOut &out);
 hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *lists,
                             uint32_t *counts, uint32_t bins_x, uint32_t bins_y, uint32_t cap);
 hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
