@@ -228,6 +228,14 @@ RWR_API int rwr_kernel_timing_stats(rwr_context *ctx, double *mean_us, uint32_t 
  * W*rows*spp primary + bounce rays actually emitted. */
 RWR_API int rwr_last_render_stats(rwr_context *ctx, uint64_t *primary_rays, uint64_t *bounce_rays);
 
+/* Self-test of the kernels' short exact forms ("Numerics"): the frame kernel replaces the
+ * shader's  ((1/d) - (1/kNear)) / ((1/kFar) - (1/kNear))  (compute.wgsl:78-80) and the three divisions
+ * of normalize() (:162) by shorter instruction sequences that return the same bits.  This runs both
+ * forms on the GPU: every float of the depth form's domain (about 2^31 inputs) and `normalize_count`
+ * pseudo-random vectors; out4 = {depth inputs compared, depth mismatches, vectors compared, vector
+ * mismatches}.  A non-zero mismatch count is a bug. */
+RWR_API int rwr_selftest_exact_math(rwr_context *ctx, uint32_t normalize_count, uint32_t seed, uint64_t out4[4]);
+
 /* ---------------------------------------------- host-side L2 surface (CPU) -- */
 
 /* CameraInvUniform::update_view_proj, src/lib.rs:105-111 with camera.rs:20-30. */

@@ -106,6 +106,7 @@ def lib() -> C.CDLL:
         "rwr_make_instance_grid": [u32, f32, vp],
         "rwr_write_png_rgba8": [C.c_char_p, vp, u32, u32, i32, i32],
         "rwr_ctx_set_kernel_timing": [vp, u32], "rwr_kernel_timing_stats": [vp, vp, vp],
+        "rwr_selftest_exact_math": [vp, u32, u32, vp],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
@@ -369,6 +370,11 @@ class Context:
         mean, n = C.c_double(), C.c_uint32()
         _check(lib().rwr_kernel_timing_stats(self._h, C.byref(mean), C.byref(n)))
         return mean.value, n.value
+
+    def selftest_exact_math(self, normalize_count: int = 1 << 30, seed: int = 1) -> tuple[int, int, int, int]:
+        out = (C.c_uint64 * 4)()
+        _check(lib().rwr_selftest_exact_math(self._h, normalize_count, seed, out))
+        return tuple(int(v) for v in out)
 
     def last_render_stats(self) -> tuple[int, int]:
         a, b = C.c_uint64(), C.c_uint64()

@@ -774,6 +774,25 @@ int rwr_kernel_timing_stats(rwr_context *ctx, double *mean_us, uint32_t *count)
     return RWR_OK;
 }
 
+int rwr_selftest_exact_math(rwr_context *ctx, uint32_t normalize_count, uint32_t seed, uint64_t out4[4])
+{
+    if (!ctx || !out4) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    DeviceGuard g(ctx->device);
+    struct Scoped {
+        DeviceBuffer<unsigned long long> b;
+        ~Scoped() { b.release(); }
+    } scoped;
+    DeviceBuffer<unsigned long long> &d_out = scoped.b;
+    RWR_HIP_CHECK(d_out.ensure(4));
+    RWR_HIP_CHECK(hipMemsetAsync(d_out.ptr, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    RWR_HIP_CHECK(launch_selftest_exact_math(ctx->stream, d_out.ptr, normalize_count, seed));
+    unsigned long long h[4];
+    RWR_HIP_CHECK(hipMemcpyAsync(h, d_out.ptr, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 4; k++) out4[k] = h[k];
+    return RWR_OK;
+}
+
 int rwr_last_render_stats(rwr_context *ctx, uint64_t *primary_rays, uint64_t *bounce_rays)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");

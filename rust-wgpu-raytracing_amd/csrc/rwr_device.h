@@ -45,20 +45,20 @@ RWR_DEV f3 normalize3(f3 a)
     return mk3(a.x / len, a.y / len, a.z / len);
 }
 // normalize3 in 21 instead of 36 divide instructions, same bits, for vectors whose components all lie
-// in [2^-100, 2^50] in magnitude (normalize_fast_domain).  a.x / len, a.y / len, a.z / len share the
+// in [2^-40, 2^40] in magnitude (normalize_fast_domain).  a.x / len, a.y / len, a.z / len share the
 // denominator, and this is the compiler's own IEEE expansion of each quotient — v_div_scale (x2),
 // v_rcp, Newton step, q = n*r, two FMA-residual corrections (the second one as v_div_fmas),
 // v_div_fixup — with the reciprocal refinement done once and the three instructions left out that
 // are the identity on such operands (ISA: v_div_scale rescales only zero / denormal / tiny numerators
-// (< 2^-103), quotients near the ends of the exponent range or exponent differences >= 96, and then sets
-// VCC for v_div_fmas; v_div_fixup replaces the quotient only for zero / infinite / NaN operands or a
-// quotient outside the exponent range).  rwr_selftest_exact_math() compares it with normalize3 on 2^30
+// (< 2^-103), denormal quotients (here every quotient is at least 2^-81) or exponent differences
+// >= 96, and then sets VCC for v_div_fmas; v_div_fixup replaces the quotient only for zero / infinite /
+// NaN operands or a quotient outside the exponent range).  rwr_selftest_exact_math() compares it with normalize3 on 2^30
 // pseudo-random in-domain vectors (tests/test_gpu_exact_math.py).
 RWR_DEV bool normalize_fast_domain(f3 a)
 {
     const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
     const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
-    return lo >= 0x1p-100f && hi <= 0x1p50f;
+    return lo >= 0x1p-40f && hi <= 0x1p40f;
 }
 RWR_DEV float div_shared_rcp(float n, float d, float r)
 {

@@ -202,6 +202,9 @@ struct FrameSetupOut {
     float4 *ray_row;   // ray_rows
     uint32_t ray_pairs, ray_rows;
 };
+// kernels_selftest.hip: out[0..3] += depth inputs compared, mismatches, normalize inputs compared, mismatches
+hipError_t launch_selftest_exact_math(hipStream_t s, unsigned long long *d_out4, uint32_t normalize_count, uint32_t seed);
+
 hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const rwr_camera_inv_uniform &cam, uint32_t width,
                               uint32_t height, const CullRec *cull, const TriRecord *tris, uint32_t n_tris,
                               const FrameSetupOut &out);
