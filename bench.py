@@ -107,6 +107,9 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
+    ap.add_argument("--frames-in-flight", type=int, default=None,
+                    help="target sets / streams the context alternates between (default: 2 for the single-GPU "
+                         "frame kernel, 1 with a gather or the wavefront integrator)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the gather path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
@@ -163,6 +166,17 @@ def main() -> int:
     assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
 
+    # Frames in flight: like a swapchain, the context owns two sets of targets and alternates between
+    # them, so one frame's kernel ramps up while the previous frame's last waves drain (at 1080p about
+    # 40 % of a lone frame kernel is its first and last waves' latency chain).  With a
+    # gather the band tensor is tied to one target set, and wavefront frames share one accumulator: 1.
+    primary_only = cfg["spp"] == 1 and cfg["bounces"] == 0
+    fif = args.frames_in_flight if args.frames_in_flight else (2 if (primary_only and not use_dist) else 1)
+    if use_dist and fif != 1:
+        print("bench.py: --frames-in-flight > 1 is not supported with the gather", file=sys.stderr)
+        return 2
+    ctx.set_frames_in_flight(fif)
+
     band = None
     gather_list = None
     if use_dist:
@@ -193,18 +207,33 @@ def main() -> int:
     # sample of the frames INSIDE the timed region (every 16th frame at most 256 brackets)
     ctx.set_kernel_timing(max(1, args.steps // 128))
     # timed region: exactly K steps; HIP events on the launch stream for the whole region
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record(stream)
+    ctx.timer_begin()            # HIP events on the launch stream(s); timer_end joins every frame in flight
     for _ in range(args.steps):
         step()
-    ev1.record(stream)
+    dev_ms = ctx.timer_end()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    dev_ms = ev0.elapsed_time(ev1)
     kernel_us, kernel_samples = ctx.kernel_timing_stats()
+    ctx.set_kernel_timing(0)
+
+    # outside the timed region: the same frames one at a time (no overlap between frames) — the latency of
+    # a frame and the duration of a lone kernel launch, reported next to the pipelined numbers
+    serial_ms_per_frame, serial_kernel_us = None, None
+    if fif > 1:
+        ctx.set_frames_in_flight(1)
+        n_serial = max(50, min(500, args.steps // 4))
+        for _ in range(10):
+            step()
+        ctx.set_kernel_timing(max(1, n_serial // 64))
+        ctx.timer_begin()
+        for _ in range(n_serial):
+            step()
+        serial_ms_per_frame = ctx.timer_end() / n_serial
+        serial_kernel_us, _ = ctx.kernel_timing_stats()
+        ctx.set_kernel_timing(0)
 
     if use_dist:
         t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -234,8 +263,10 @@ def main() -> int:
             # one-workgroup k_frame_setup that precedes it on the same stream)
             algo_bytes = ALGO_BYTES_PER_PIXEL * w * (r1 - r0)
             kernel = "k_primary"
-            note = ("8 B/pixel (RGBA8 + R32F store, each pixel once); the scene (12 KB + 1 MiB texture) is cache resident, "
-                    "so the kernel is VALU-bound: see roofline.valu and DESIGN.md")
+            note = ("8 B/pixel (RGBA8 + R32F store, each pixel once); the scene (face records + 4 MiB linear-float texture) is "
+                    "cache resident, so the kernel is bound by its arithmetic and its latency chain, not by HBM: DESIGN.md §4.1. "
+                    "launch_us is the duration of a launch INSIDE the timed region, where two frames are in flight and "
+                    "their kernels share the GPU; launch_us_serial is a lone launch")
         else:
             # wavefront: SURVEY §8(d) contract figure, 96 B per path segment + 20 B per pixel per frame
             algo_bytes = int(96 * rays_per_frame / world + 20 * w * (r1 - r0))
@@ -257,15 +288,19 @@ def main() -> int:
             "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(launch_s * 1e6, 3),
             "launch_us_samples": kernel_samples, "step_us_on_stream": round(dev_ms * 1e3 / args.steps, 3), "note": note,
         }
+        if serial_kernel_us:
+            roofline["launch_us_serial"] = round(serial_kernel_us, 3)
         out = {
             "metric": "Mray/s", "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "ms_per_frame": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["label"], "width": w, "height": h, "spp": cfg["spp"], "bounces": cfg["bounces"],
                        "faces": int(len(model["faces"])), "partition": f"{world} row band(s) + 1 RCCL gather" if world > 1 else "single GPU",
-                       "device": info["name"]},
+                       "frames_in_flight": fif, "device": info["name"]},
             "roofline": roofline,
         }
+        if serial_ms_per_frame is not None:
+            out["ms_per_frame_one_in_flight"] = round(serial_ms_per_frame, 5)   # frame latency: each frame waits for the previous
         if gathered_ok is not None:
             out["config"]["gathered_frame_ok"] = gathered_ok
     ctx.close()

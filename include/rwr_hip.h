@@ -142,6 +142,16 @@ RWR_API int rwr_device_count(int *out_count);
 /* Name, CU count and wavefront size of the context's device. */
 RWR_API int rwr_ctx_device_info(rwr_context *ctx, char *name, size_t name_cap, int *cu_count, int *wave_size);
 
+/* Frames in flight (1..3, default 1).  With n > 1 the context owns n sets of targets and per-frame
+ * buffers, each with its own HIP stream, and consecutive rwr_render calls take them in turn, the way a
+ * swapchain hands out images (the reference presents through wgpu's surface, lib.rs:1186-1187): the
+ * next frame's kernels fill the GPU while the previous frame's last waves drain.  rwr_readback and
+ * rwr_get_device_targets refer to the frame rendered last and wait for that frame only; a frame's
+ * targets stay valid until n further frames have been rendered.  rwr_synchronize, scene changes,
+ * rwr_resize and rwr_ctx_set_stream wait for all frames in flight.  Slot 0 uses the context's stream
+ * (rwr_ctx_set_stream), the others internal streams. */
+RWR_API int rwr_ctx_set_frames_in_flight(rwr_context *ctx, uint32_t n);
+
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of
  * the context's own stream.  NULL restores the context's stream. */
 RWR_API int rwr_ctx_set_stream(rwr_context *ctx, void *hip_stream);

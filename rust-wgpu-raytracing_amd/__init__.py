@@ -106,7 +106,7 @@ def lib() -> C.CDLL:
         "rwr_make_instance_grid": [u32, f32, vp],
         "rwr_write_png_rgba8": [C.c_char_p, vp, u32, u32, i32, i32],
         "rwr_ctx_set_kernel_timing": [vp, u32], "rwr_kernel_timing_stats": [vp, vp, vp],
-        "rwr_selftest_exact_math": [vp, u32, u32, vp],
+        "rwr_selftest_exact_math": [vp, u32, u32, vp], "rwr_ctx_set_frames_in_flight": [vp, u32],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
@@ -362,6 +362,9 @@ class Context:
         ms = C.c_float()
         _check(lib().rwr_timer_end(self._h, C.byref(ms)))
         return ms.value
+
+    def set_frames_in_flight(self, n: int):
+        _check(lib().rwr_ctx_set_frames_in_flight(self._h, n))
 
     def set_kernel_timing(self, every_n: int):
         _check(lib().rwr_ctx_set_kernel_timing(self._h, every_n))

@@ -63,11 +63,40 @@ struct DeviceBuffer {
 
 using namespace rwr;
 
+// Everything one frame in flight owns: its stream, its targets and the per-frame records / tables.
+// Frames alternate between slots (rwr_ctx_set_frames_in_flight), so the ramp-up of one frame's kernel
+// fills the machine while the previous frame's last waves drain; a slot is reused in stream order.
+struct FrameSlot {
+    hipStream_t stream = nullptr;   // slot 0: the context's stream (may be the caller's); others: owned
+    hipStream_t owned = nullptr;
+    hipEvent_t done = nullptr;      // rwr_timer_end: joins the slot into the timing stream
+    DeviceBuffer<uint8_t> d_color;
+    DeviceBuffer<float> d_depth;
+    DeviceBuffer<float> d_color_f32;
+    DeviceBuffer<int32_t> d_obj_id;
+    DeviceBuffer<float> d_hit_t;
+    DeviceBuffer<FrameTri> d_ftris;
+    DeviceBuffer<float> d_tnum;                  // per frame: plane-distance numerator per face
+    DeviceBuffer<float4> d_ray_colp, d_ray_row;  // per frame: ray tables (FrameParams::ray_colp / ray_row)
+    DeviceBuffer<uint32_t> d_bin_lists, d_bin_counts;   // per-frame screen bins (large scenes)
+    bool aux_valid = false;
+    void release_buffers()
+    {
+        d_color.release(); d_depth.release(); d_color_f32.release(); d_obj_id.release(); d_hit_t.release();
+        d_ftris.release(); d_tnum.release(); d_ray_colp.release(); d_ray_row.release();
+        d_bin_lists.release(); d_bin_counts.release();
+    }
+};
+constexpr uint32_t kMaxFramesInFlight = 3;
+
 struct rwr_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // == slots[0].stream
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    FrameSlot slots[kMaxFramesInFlight];
+    uint32_t n_slots = 1;           // frames in flight
+    uint32_t cur = 0;               // slot of the most recent frame
 
     // scene
     DeviceBuffer<rwr_model_vertex_small> d_verts;
@@ -76,10 +105,6 @@ struct rwr_context {
     DeviceBuffer<TriRecord> d_tris;
     DeviceBuffer<ShadeRec> d_shade;
     DeviceBuffer<CullRec> d_cull;
-    DeviceBuffer<FrameTri> d_ftris;
-    DeviceBuffer<float> d_tnum;              // per frame: plane-distance numerator per face
-    DeviceBuffer<float4> d_ray_colp, d_ray_row;  // per frame: ray tables (FrameParams::ray_colp / ray_row)
-    DeviceBuffer<uint32_t> d_bin_lists, d_bin_counts;   // per-frame screen bins (large scenes)
     uint32_t bin_min_faces = 256;                       // tunable: RWR_BIN_MIN_FACES
     bool force_one_pixel = false;                       // debug: RWR_ONE_PIXEL_PER_LANE=1
     // BVH over the (flattened) world-space faces, for bounce rays
@@ -112,12 +137,6 @@ struct rwr_context {
 
     // targets
     rwr_screen screen{0, 0};
-    DeviceBuffer<uint8_t> d_color;
-    DeviceBuffer<float> d_depth;
-    DeviceBuffer<float> d_color_f32;
-    DeviceBuffer<int32_t> d_obj_id;
-    DeviceBuffer<float> d_hit_t;
-    bool aux_valid = false;
 
     uint64_t last_primary = 0, last_bounce = 0;
     // optional per-kernel timing (rwr_ctx_set_kernel_timing)
@@ -143,6 +162,30 @@ struct DeviceGuard {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+
+// Waits for every frame in flight (scene changes, resizes, stream changes and teardown need an idle context).
+hipError_t sync_all(rwr_context *ctx)
+{
+    hipError_t first = hipSuccess;
+    for (uint32_t i = 0; i < kMaxFramesInFlight; i++) {
+        if (!ctx->slots[i].stream) continue;
+        const hipError_t e = hipStreamSynchronize(ctx->slots[i].stream);
+        if (first == hipSuccess) first = e;
+    }
+    return first;
+}
+
+// Targets of slot `i` for the current screen (the reference's textures start zeroed and are cleared every frame).
+hipError_t ensure_slot_targets(rwr_context *ctx, uint32_t i)
+{
+    FrameSlot &sl = ctx->slots[i];
+    const size_t n = (size_t)ctx->screen.width * ctx->screen.height;
+    if (n == 0) return hipSuccess;
+    hipError_t e;
+    if ((e = sl.d_color.ensure(n * 4)) != hipSuccess || (e = sl.d_depth.ensure(n)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(sl.d_color.ptr, 0, n * 4, sl.stream)) != hipSuccess) return e;
+    return hipMemsetAsync(sl.d_depth.ptr, 0, n * sizeof(float), sl.stream);
+}
 
 void build_srgb_lut(float *lut)
 {
@@ -261,8 +304,6 @@ int rebuild_tris(rwr_context *ctx)
     RWR_HIP_CHECK(ctx->d_tris.ensure(total));
     RWR_HIP_CHECK(ctx->d_shade.ensure(total));
     RWR_HIP_CHECK(ctx->d_cull.ensure(total));
-    RWR_HIP_CHECK(ctx->d_ftris.ensure(total));
-    RWR_HIP_CHECK(ctx->d_tnum.ensure(total));
     RWR_HIP_CHECK(launch_prebake(ctx->stream, ctx->d_verts.ptr, ctx->d_faces.ptr, ctx->d_face_mat.ptr, ctx->n_faces, ctx->d_instances.ptr,
                                  ctx->n_instances, ctx->d_materials.ptr, ctx->d_tris.ptr, ctx->d_shade.ptr, ctx->d_cull.ptr));
     // BVH for incoherent rays, built on the host from the device's own world-space corners
@@ -334,6 +375,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
         return set_error(RWR_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
     }
     ctx->stream = ctx->own_stream;
+    ctx->slots[0].stream = ctx->stream;
     if (const char *e2 = std::getenv("RWR_WAVE_CULL_MIN")) ctx->wave_cull_min = (uint32_t)std::strtoul(e2, nullptr, 10);
     if (const char *e4 = std::getenv("RWR_ONE_PIXEL_PER_LANE")) ctx->force_one_pixel = std::atoi(e4) != 0;
     if (const char *e3 = std::getenv("RWR_BIN_MIN_FACES")) ctx->bin_min_faces = (uint32_t)std::strtoul(e3, nullptr, 10);
@@ -345,14 +387,17 @@ void rwr_ctx_destroy(rwr_context *ctx)
 {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)sync_all(ctx);
     ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
-    ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release(); ctx->d_ftris.release(); ctx->d_tnum.release(); ctx->d_ray_colp.release(); ctx->d_ray_row.release(); ctx->d_bin_lists.release(); ctx->d_bin_counts.release();
+    ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
     ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_seg_count.release(); ctx->d_seg_total.release(); for (auto &t : ctx->d_texs) t.release();
     ctx->d_face_mat.release(); ctx->d_materials.release();
-    ctx->d_color.release(); ctx->d_depth.release(); ctx->d_color_f32.release();
-    ctx->d_obj_id.release(); ctx->d_hit_t.release();
+    for (FrameSlot &sl : ctx->slots) {
+        sl.release_buffers();
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.owned) (void)hipStreamDestroy(sl.owned);
+    }
     for (hipEvent_t e : ctx->timing_events) (void)hipEventDestroy(e);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
@@ -377,8 +422,9 @@ int rwr_ctx_set_stream(rwr_context *ctx, void *hip_stream)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
     DeviceGuard g(ctx->device);
-    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    RWR_HIP_CHECK(sync_all(ctx));
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->slots[0].stream = ctx->stream;
     return RWR_OK;
 }
 
@@ -388,7 +434,7 @@ int rwr_scene_clear(rwr_context *ctx)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
     DeviceGuard g(ctx->device);
-    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    RWR_HIP_CHECK(sync_all(ctx));
     ctx->st_verts.clear(); ctx->st_faces.clear(); ctx->st_face_mat.clear(); ctx->st_materials.clear();
     for (auto &t : ctx->d_texs) t.release();
     ctx->d_texs.clear();
@@ -458,7 +504,7 @@ int rwr_scene_commit(rwr_context *ctx)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
     DeviceGuard g(ctx->device);
-    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    RWR_HIP_CHECK(sync_all(ctx));
     ctx->n_faces = (uint32_t)ctx->st_faces.size();
     ctx->n_verts = (uint32_t)ctx->st_verts.size();
     ctx->n_tris = 0;
@@ -507,7 +553,7 @@ int rwr_scene_set_instances(rwr_context *ctx, const rwr_instance_raw *instances,
     if (n && !instances) return set_error(RWR_ERR_INVALID_ARGUMENT, "instances is NULL");
     if ((uint64_t)ctx->n_faces * (n ? n : 1u) > 0x7fffffffull) return set_error(RWR_ERR_INVALID_ARGUMENT, "too many faces");
     DeviceGuard g(ctx->device);
-    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    RWR_HIP_CHECK(sync_all(ctx));
     if (n) {
         RWR_HIP_CHECK(ctx->d_instances.ensure(n));
         RWR_HIP_CHECK(hipMemcpy(ctx->d_instances.ptr, instances, (size_t)n * sizeof *instances, hipMemcpyHostToDevice));
@@ -527,15 +573,12 @@ int rwr_resize(rwr_context *ctx, const rwr_screen *screen)
     if (screen->width == 0 || screen->height == 0) return set_error(RWR_ERR_INVALID_ARGUMENT, "zero-sized screen");
     if ((uint64_t)screen->width * screen->height > (1ull << 30)) return set_error(RWR_ERR_INVALID_ARGUMENT, "screen too large");
     DeviceGuard g(ctx->device);
-    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const size_t n = (size_t)screen->width * screen->height;
-    RWR_HIP_CHECK(ctx->d_color.ensure(n * 4));
-    RWR_HIP_CHECK(ctx->d_depth.ensure(n));
-    // the reference's textures start zeroed and are cleared every frame
-    RWR_HIP_CHECK(hipMemsetAsync(ctx->d_color.ptr, 0, n * 4, ctx->stream));
-    RWR_HIP_CHECK(hipMemsetAsync(ctx->d_depth.ptr, 0, n * sizeof(float), ctx->stream));
+    RWR_HIP_CHECK(sync_all(ctx));
     ctx->screen = *screen;
-    ctx->aux_valid = false;
+    for (uint32_t i = 0; i < ctx->n_slots; i++) {
+        RWR_HIP_CHECK(ensure_slot_targets(ctx, i));
+        ctx->slots[i].aux_valid = false;
+    }
     return RWR_OK;
 }
 
@@ -560,13 +603,24 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     DeviceGuard g(ctx->device);
     const size_t n = (size_t)ctx->screen.width * ctx->screen.height;
     const bool aux = (rp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
-    if (aux) {
-        RWR_HIP_CHECK(ctx->d_color_f32.ensure(n * 4));
-        RWR_HIP_CHECK(ctx->d_obj_id.ensure(n));
-        RWR_HIP_CHECK(ctx->d_hit_t.ensure(n));
-    }
     int rc = rebuild_tris(ctx);
     if (rc != RWR_OK) return rc;
+    // Frame slot: the next one in turn.  A frame of the wavefront integrator uses the context's single
+    // accumulator and ray queue, so it first waits for the frame before it (milliseconds of work: nothing
+    // to gain from overlap), and so does the frame after it.
+    const uint32_t prev = ctx->cur;
+    ctx->cur = (ctx->cur + 1u) % ctx->n_slots;
+    FrameSlot &sl = ctx->slots[ctx->cur];
+    if (ctx->n_slots > 1u && (wavefront || ctx->last_spp != 0u)) RWR_HIP_CHECK(hipStreamSynchronize(ctx->slots[prev].stream));
+    const hipStream_t stream = sl.stream;
+    if (aux) {
+        RWR_HIP_CHECK(sl.d_color_f32.ensure(n * 4));
+        RWR_HIP_CHECK(sl.d_obj_id.ensure(n));
+        RWR_HIP_CHECK(sl.d_hit_t.ensure(n));
+    }
+    const uint32_t total_tris = ctx->n_tris;
+    RWR_HIP_CHECK(sl.d_ftris.ensure(total_tris));
+    RWR_HIP_CHECK(sl.d_tnum.ensure(total_tris));
 
     FrameParams fp{};
     fp.cam = *camera;
@@ -590,8 +644,8 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     fp.materials = ctx->d_materials.ptr;
     fp.n_materials = (uint32_t)ctx->st_materials.size();
     const float4 *tex0 = ctx->d_texs.empty() ? nullptr : ctx->d_texs[0].ptr;
-    Targets tg{ctx->d_color.ptr, ctx->d_depth.ptr, aux ? ctx->d_color_f32.ptr : nullptr,
-               aux ? ctx->d_obj_id.ptr : nullptr, aux ? ctx->d_hit_t.ptr : nullptr};
+    Targets tg{sl.d_color.ptr, sl.d_depth.ptr, aux ? sl.d_color_f32.ptr : nullptr,
+               aux ? sl.d_obj_id.ptr : nullptr, aux ? sl.d_hit_t.ptr : nullptr};
     CullConsts cc;
     compute_cull_consts(*camera, ctx->screen.width, ctx->screen.height, cc);
     compute_sphere_rects(cc, ctx->spheres, ctx->n_spheres, ctx->screen.width, ctx->screen.height, fp.sphere_rect);
@@ -607,11 +661,11 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         FrameSetupOut so{};
         so.ray_pairs = ((ctx->screen.width + 63u) / 64u) * 32u;  // whole 64-pixel workgroup columns
         so.ray_rows = ctx->screen.height + 8u;                   // whole 8-row tiles below any band
-        RWR_HIP_CHECK(ctx->d_ray_colp.ensure(2u * (size_t)so.ray_pairs));
-        RWR_HIP_CHECK(ctx->d_ray_row.ensure(so.ray_rows));
-        so.ftris = ctx->d_ftris.ptr; so.tnum = ctx->d_tnum.ptr;
-        so.ray_colp = ctx->d_ray_colp.ptr; so.ray_row = ctx->d_ray_row.ptr;
-        RWR_HIP_CHECK(launch_frame_setup(ctx->stream, cc, *camera, ctx->screen.width, ctx->screen.height, ctx->d_cull.ptr,
+        RWR_HIP_CHECK(sl.d_ray_colp.ensure(2u * (size_t)so.ray_pairs));
+        RWR_HIP_CHECK(sl.d_ray_row.ensure(so.ray_rows));
+        so.ftris = sl.d_ftris.ptr; so.tnum = sl.d_tnum.ptr;
+        so.ray_colp = sl.d_ray_colp.ptr; so.ray_row = sl.d_ray_row.ptr;
+        RWR_HIP_CHECK(launch_frame_setup(stream, cc, *camera, ctx->screen.width, ctx->screen.height, ctx->d_cull.ptr,
                                          ctx->d_tris.ptr, ctx->n_tris, so));
         fp.ray_colp = so.ray_colp; fp.ray_row = so.ray_row; fp.tnum = so.tnum;
     }
@@ -621,11 +675,11 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         const bool bins_fit = (uint64_t)bins_x * bins_y * ctx->n_tris * sizeof(uint32_t) <= (2ull << 30);
         if (ctx->n_tris > ctx->bin_min_faces && bins_fit) {
             // more faces than one 256-wide batch: bin them per 64x32-pixel screen region, once per frame
-            RWR_HIP_CHECK(ctx->d_bin_lists.ensure((size_t)bins_x * bins_y * ctx->n_tris));
-            RWR_HIP_CHECK(ctx->d_bin_counts.ensure((size_t)bins_x * bins_y));
-            RWR_HIP_CHECK(launch_bin_faces(ctx->stream, ctx->d_ftris.ptr, ctx->n_tris, row_begin, ctx->d_bin_lists.ptr,
-                                           ctx->d_bin_counts.ptr, bins_x, bins_y, ctx->n_tris));
-            fp.bins = BinGrid{ctx->d_bin_lists.ptr, ctx->d_bin_counts.ptr, bins_x, bins_y, ctx->n_tris, 1u};
+            RWR_HIP_CHECK(sl.d_bin_lists.ensure((size_t)bins_x * bins_y * ctx->n_tris));
+            RWR_HIP_CHECK(sl.d_bin_counts.ensure((size_t)bins_x * bins_y));
+            RWR_HIP_CHECK(launch_bin_faces(stream, sl.d_ftris.ptr, ctx->n_tris, row_begin, sl.d_bin_lists.ptr,
+                                           sl.d_bin_counts.ptr, bins_x, bins_y, ctx->n_tris));
+            fp.bins = BinGrid{sl.d_bin_lists.ptr, sl.d_bin_counts.ptr, bins_x, bins_y, ctx->n_tris, 1u};
         }
     }
     const bool time_this = ctx->timing_every && (ctx->timing_calls++ % ctx->timing_every == 0) && ctx->timing_pairs < 256;
@@ -641,16 +695,16 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     // the two-pixel frame kernel is timed by its own dispatch timestamps; everything else by stream events
     const bool dispatch_timed = time_this && !wavefront && !(rp.flags & RWR_FLAG_USE_BVH) &&
                                 !((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel);
-    if (time_this && !dispatch_timed) RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs], ctx->stream));
+    if (time_this && !dispatch_timed) RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs], stream));
     if (!wavefront && (rp.flags & RWR_FLAG_USE_BVH)) {
         const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
-        RWR_HIP_CHECK(launch_primary_bvh(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh_p, tex0, tg));
+        RWR_HIP_CHECK(launch_primary_bvh(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh_p, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront) {
         if ((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel)
-            RWR_HIP_CHECK(launch_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, ctx->d_ftris.ptr, tex0, tg));
+            RWR_HIP_CHECK(launch_primary(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0, tg));
         else
-            RWR_HIP_CHECK(launch_primary_p2(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, ctx->d_ftris.ptr, tex0, tg,
+            RWR_HIP_CHECK(launch_primary_p2(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0, tg,
                                             dispatch_timed ? ctx->timing_events[2 * ctx->timing_pairs] : nullptr,
                                             dispatch_timed ? ctx->timing_events[2 * ctx->timing_pairs + 1] : nullptr));
         ctx->last_spp = 0;
@@ -670,22 +724,22 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
         for (uint32_t sidx = 0; sidx < rp.spp; sidx++) {
             fp.sample = sidx;
-            RWR_HIP_CHECK(launch_wf_primary(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, ctx->d_ftris.ptr, tex0,
+            RWR_HIP_CHECK(launch_wf_primary(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0,
                                             tg, wf));
             if (rp.max_bounces)
-                RWR_HIP_CHECK(launch_wf_bounce(ctx->stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh, tex0,
+                RWR_HIP_CHECK(launch_wf_bounce(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh, tex0,
                                                wf, n_segments));
         }
-        RWR_HIP_CHECK(launch_wf_resolve(ctx->stream, fp, tg, wf));
+        RWR_HIP_CHECK(launch_wf_resolve(stream, fp, tg, wf));
         ctx->last_spp = rp.spp;
         ctx->last_segments = n_segments;
         ctx->last_had_bounce = rp.max_bounces != 0;
     }
     if (time_this) {
-        if (!dispatch_timed) RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs + 1], ctx->stream));
+        if (!dispatch_timed) RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs + 1], stream));
         ctx->timing_pairs++;
     }
-    ctx->aux_valid = aux;
+    sl.aux_valid = aux;
     ctx->last_primary = (uint64_t)ctx->screen.width * (row_end - row_begin) * rp.spp;
     ctx->last_bounce = 0;  // filled in lazily by rwr_last_render_stats from the pass counters
     return RWR_OK;
@@ -701,7 +755,7 @@ int rwr_synchronize(rwr_context *ctx)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
     DeviceGuard g(ctx->device);
-    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    RWR_HIP_CHECK(sync_all(ctx));
     return RWR_OK;
 }
 
@@ -709,16 +763,16 @@ int rwr_readback(rwr_context *ctx, uint8_t *rgba8, float *depth, float *rgba_f32
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (ctx->screen.width == 0) return set_error(RWR_ERR_NOT_READY, "rwr_resize has not been called");
-    if ((rgba_f32 || obj_id || hit_t) && !ctx->aux_valid)
+    if ((rgba_f32 || obj_id || hit_t) && !ctx->slots[ctx->cur].aux_valid)
         return set_error(RWR_ERR_NOT_READY, "aux planes requested but the last render did not set RWR_FLAG_AUX_OUTPUTS");
     DeviceGuard g(ctx->device);
     const size_t n = (size_t)ctx->screen.width * ctx->screen.height;
-    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (rgba8) RWR_HIP_CHECK(hipMemcpy(rgba8, ctx->d_color.ptr, n * 4, hipMemcpyDeviceToHost));
-    if (depth) RWR_HIP_CHECK(hipMemcpy(depth, ctx->d_depth.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
-    if (rgba_f32) RWR_HIP_CHECK(hipMemcpy(rgba_f32, ctx->d_color_f32.ptr, n * 4 * sizeof(float), hipMemcpyDeviceToHost));
-    if (obj_id) RWR_HIP_CHECK(hipMemcpy(obj_id, ctx->d_obj_id.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (hit_t) RWR_HIP_CHECK(hipMemcpy(hit_t, ctx->d_hit_t.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->slots[ctx->cur].stream));
+    if (rgba8) RWR_HIP_CHECK(hipMemcpy(rgba8, ctx->slots[ctx->cur].d_color.ptr, n * 4, hipMemcpyDeviceToHost));
+    if (depth) RWR_HIP_CHECK(hipMemcpy(depth, ctx->slots[ctx->cur].d_depth.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (rgba_f32) RWR_HIP_CHECK(hipMemcpy(rgba_f32, ctx->slots[ctx->cur].d_color_f32.ptr, n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    if (obj_id) RWR_HIP_CHECK(hipMemcpy(obj_id, ctx->slots[ctx->cur].d_obj_id.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (hit_t) RWR_HIP_CHECK(hipMemcpy(hit_t, ctx->slots[ctx->cur].d_hit_t.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
     return RWR_OK;
 }
 
@@ -726,8 +780,35 @@ int rwr_get_device_targets(rwr_context *ctx, void **d_rgba8, void **d_depth)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (ctx->screen.width == 0) return set_error(RWR_ERR_NOT_READY, "rwr_resize has not been called");
-    if (d_rgba8) *d_rgba8 = ctx->d_color.ptr;
-    if (d_depth) *d_depth = ctx->d_depth.ptr;
+    if (d_rgba8) *d_rgba8 = ctx->slots[ctx->cur].d_color.ptr;
+    if (d_depth) *d_depth = ctx->slots[ctx->cur].d_depth.ptr;
+    return RWR_OK;
+}
+
+int rwr_ctx_set_frames_in_flight(rwr_context *ctx, uint32_t n)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (n < 1u || n > kMaxFramesInFlight)
+        return set_error(RWR_ERR_INVALID_ARGUMENT, "frames in flight must be 1..%u", kMaxFramesInFlight);
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(sync_all(ctx));
+    for (uint32_t i = 1; i < n; i++) {
+        FrameSlot &sl = ctx->slots[i];
+        if (!sl.owned) RWR_HIP_CHECK(hipStreamCreateWithFlags(&sl.owned, hipStreamNonBlocking));
+        if (!sl.done) RWR_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        sl.stream = sl.owned;
+    }
+    for (uint32_t i = n; i < kMaxFramesInFlight; i++) {  // slots no longer used give their memory back
+        if (i == 0) continue;
+        ctx->slots[i].release_buffers();
+        ctx->slots[i].aux_valid = false;
+    }
+    // the most recent frame stays where it is if its slot survives, otherwise it is gone
+    ctx->n_slots = n;
+    if (ctx->cur >= n) ctx->cur = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (!ctx->slots[i].d_color.ptr) RWR_HIP_CHECK(ensure_slot_targets(ctx, i));
+    RWR_HIP_CHECK(sync_all(ctx));
     return RWR_OK;
 }
 
@@ -735,6 +816,7 @@ int rwr_timer_begin(rwr_context *ctx)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
     DeviceGuard g(ctx->device);
+    if (ctx->n_slots > 1u) RWR_HIP_CHECK(sync_all(ctx));  // the interval starts with nothing in flight
     RWR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
     return RWR_OK;
 }
@@ -743,6 +825,10 @@ int rwr_timer_end(rwr_context *ctx, float *elapsed_ms)
 {
     if (!ctx || !elapsed_ms) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
     DeviceGuard g(ctx->device);
+    for (uint32_t i = 1; i < ctx->n_slots; i++) {  // the interval ends when every frame in flight has ended
+        RWR_HIP_CHECK(hipEventRecord(ctx->slots[i].done, ctx->slots[i].stream));
+        RWR_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->slots[i].done, 0));
+    }
     RWR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
     RWR_HIP_CHECK(hipEventSynchronize(ctx->ev_end));
     RWR_HIP_CHECK(hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
@@ -762,7 +848,7 @@ int rwr_kernel_timing_stats(rwr_context *ctx, double *mean_us, uint32_t *count)
 {
     if (!ctx || !mean_us || !count) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
     DeviceGuard g(ctx->device);
-    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    RWR_HIP_CHECK(sync_all(ctx));
     double sum = 0.0;
     for (uint32_t i = 0; i < ctx->timing_pairs; i++) {
         float ms = 0.0f;
@@ -799,7 +885,7 @@ int rwr_last_render_stats(rwr_context *ctx, uint64_t *primary_rays, uint64_t *bo
     if (ctx->last_spp && ctx->last_had_bounce) {
         DeviceGuard g(ctx->device);
         std::vector<uint32_t> counts(ctx->last_segments);
-        RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        RWR_HIP_CHECK(hipStreamSynchronize(ctx->slots[ctx->cur].stream));
         RWR_HIP_CHECK(hipMemcpy(counts.data(), ctx->d_seg_total.ptr, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         ctx->last_bounce = 0;
         for (uint32_t c : counts) ctx->last_bounce += c;

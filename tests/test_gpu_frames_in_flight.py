@@ -1,0 +1,46 @@
+"""rwr_ctx_set_frames_in_flight: frames alternate between target sets / streams; every frame must be
+the frame a single-slot context renders, and the frame rendered last is the one read back."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.gpu
+def test_frames_in_flight_give_the_same_frames(rwr, gpu_ctx, suzanne):
+    w, h = 200, 120
+    cams = [rwr.camera_build_inv_uniform(rwr.make_camera(eye=e, aspect=w / h)) for e in ((0, 0, 0), (0, 0, 3), (1.5, 0.5, 2.5), (0, 1, 4))]
+    gpu_ctx.upload_model(suzanne); gpu_ctx.set_spheres(rwr.make_spheres(rwr.REFERENCE_SPHERES)); gpu_ctx.resize(w, h)
+    gpu_ctx.set_frames_in_flight(1)
+    want = []
+    for c in cams:
+        gpu_ctx.render(c, rwr.make_params(flags=rwr.FLAG_AUX_OUTPUTS))
+        want.append(gpu_ctx.readback(aux=True))
+    try:
+        for n in (2, 3):
+            gpu_ctx.set_frames_in_flight(n)
+            # read every frame right after it was queued
+            for c, ref in zip(cams, want):
+                gpu_ctx.render(c, rwr.make_params(flags=rwr.FLAG_AUX_OUTPUTS))
+                got = gpu_ctx.readback(aux=True)
+                for k in ("color", "depth", "obj_id", "hit_t", "color_f32"):
+                    assert np.array_equal(got[k], ref[k]), (n, k)
+            # queue them all, read the last: it is the last camera's frame
+            for c in cams:
+                gpu_ctx.render(c, rwr.make_params())
+            got = gpu_ctx.readback()
+            assert np.array_equal(got["color"], want[-1]["color"]) and np.array_equal(got["depth"], want[-1]["depth"])
+            # a path-traced frame between primary frames (shared accumulator: it must wait for its neighbours)
+            gpu_ctx.render(cams[1], rwr.make_params())
+            gpu_ctx.render(cams[0], rwr.make_params(spp=2, max_bounces=1, seed=3))
+            pt = gpu_ctx.readback()
+            gpu_ctx.render(cams[1], rwr.make_params())
+            after = gpu_ctx.readback()
+            assert np.array_equal(after["color"], want[1]["color"])
+            gpu_ctx.set_frames_in_flight(1)
+            gpu_ctx.render(cams[0], rwr.make_params(spp=2, max_bounces=1, seed=3))
+            assert np.array_equal(gpu_ctx.readback()["color"], pt["color"])
+    finally:
+        gpu_ctx.set_frames_in_flight(1)
+    with pytest.raises(rwr.RwrError):
+        gpu_ctx.set_frames_in_flight(0)
+    with pytest.raises(rwr.RwrError):
+        gpu_ctx.set_frames_in_flight(4)
