@@ -1,7 +1,7 @@
 // Self-test of the short exact forms (rwr_device.h): they must return the very bits of the
 // expressions they stand in for, on this GPU, for every input of their stated domain.
-//   * to_non_linear_depth_fast vs to_non_linear_depth: ALL 2^32 float bit patterns are visited and
-//     every one inside depth_fast_domain is compared (scalar and two-wide forms);
+//   * to_non_linear_depth_fast vs to_non_linear_depth, sqrt_fast vs sqrtf: ALL 2^32 float bit patterns
+//     are visited and every one inside the form's domain is compared (scalar and two-wide forms);
 //   * normalize3_fast vs normalize3: 2^30 pseudo-random vectors spread over the whole domain of
 //     normalize_fast_domain and a little beyond it (exponents 2^-44 .. 2^43 per component, all sign combinations;
 //     vectors outside the domain are skipped, as the kernel skips them), plus the
@@ -20,6 +20,11 @@ k_selftest_depth(unsigned long long *out)  // out[0] compared, out[1] mismatches
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
         const float t = __uint_as_float((uint32_t)i);
+        if (t >= 0x1p-100f && t <= 0x1p100f) {  // sqrt_fast's range
+            const f2 sq = sqrt_fast(f2{t, t});
+            const float want_sq = sqrtf(t);
+            bad += !(same_bits(sqrt_fast(t), want_sq) && same_bits(sq.x, want_sq) && same_bits(sq.y, want_sq));
+        }
         if (!depth_fast_domain(t)) continue;
         const float want = to_non_linear_depth(t);
         const f2 pair = to_non_linear_depth_fast(f2{t, t});

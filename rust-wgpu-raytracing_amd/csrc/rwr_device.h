@@ -44,7 +44,7 @@ RWR_DEV f3 normalize3(f3 a)
     float len = sqrtf(dot3(a, a));
     return mk3(a.x / len, a.y / len, a.z / len);
 }
-// normalize3 in 21 instead of 36 divide instructions, same bits, for vectors whose components all lie
+// normalize3's three divisions in 18 instead of 33 instructions (and its sqrt in 5 instead of 14), same bits, for vectors whose components all lie
 // in [2^-40, 2^40] in magnitude (normalize_fast_domain).  a.x / len, a.y / len, a.z / len share the
 // denominator, and this is the compiler's own IEEE expansion of each quotient — v_div_scale (x2),
 // v_rcp, Newton step, q = n*r, two FMA-residual corrections (the second one as v_div_fmas),
@@ -66,9 +66,20 @@ RWR_DEV float div_shared_rcp(float n, float d, float r)
     const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r, q0);
     return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r, q1);
 }
+// sqrtf in 5 instead of 14 instructions, same bits, for 2^-100 <= x <= 2^100: v_rsq_f32, g = x * y,
+// one FMA-residual correction with h = y / 2.  By exhaustion (tools/ubench/exact_sqrt.hip: the only
+// mismatches against the IEEE expansion are below 2^-102, where the residual underflows;
+// rwr_selftest_exact_math() re-checks every float of the range).  dot(a, a) of a vector of
+// normalize_fast_domain lies in [2^-80, 2^82].
+RWR_DEV float sqrt_fast(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    return __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
+}
 RWR_DEV f3 normalize3_fast(f3 a)
 {
-    const float len = sqrtf(dot3(a, a));
+    const float len = sqrt_fast(dot3(a, a));
     float r = __builtin_amdgcn_rcpf(len);
     r = __builtin_fmaf(__builtin_fmaf(-len, r, 1.0f), r, r);
     return mk3(div_shared_rcp(a.x, len, r), div_shared_rcp(a.y, len, r), div_shared_rcp(a.z, len, r));
@@ -283,14 +294,20 @@ RWR_DEV Shaded shade_mesh(const ShadeRec &S, float eu, float ev, float ndotd, f3
     return r;
 }
 
-// rgba8unorm store conversion: clamp, scale, round half up.  The clamp is applied after the scale
-// (med3 of c * 255 + 0.5 against [0.5, 255.5] = the clamp of c against [0, 1] carried through the
-// monotonic map; a NaN gives 0 like fmin(fmax(c, 0), 1)).
-RWR_DEV uint32_t unorm8_scaled(float v) { return (uint32_t)__builtin_amdgcn_fmed3f(v, 0.5f, 255.5f); }
-RWR_DEV uint32_t unorm8(float c) { return unorm8_scaled(__builtin_fmaf(c, 255.0f, 0.5f)); }
+// rgba8unorm store conversion, one v_cvt_pk_u8_f32 per channel: it saturates to [0, 255] (NaN -> 0)
+// and rounds to nearest (ties to even where the texture-store rule rounds half up: an exact tie moves
+// the byte by one LSB, like any 1e-7 difference next to a rounding boundary does).
+RWR_DEV uint32_t pack_rgba8_scaled(float r255, float g255, float b255, uint32_t alpha_bits)
+{
+    uint32_t v = alpha_bits;
+    v = __builtin_amdgcn_cvt_pk_u8_f32(r255, 0, v);
+    v = __builtin_amdgcn_cvt_pk_u8_f32(g255, 1, v);
+    return __builtin_amdgcn_cvt_pk_u8_f32(b255, 2, v);
+}
 RWR_DEV uint32_t pack_rgba8(float r, float g, float b, float a)
 {
-    return unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | (unorm8(a) << 24);
+    const uint32_t alpha = __builtin_amdgcn_cvt_pk_u8_f32(a * 255.0f, 3, 0u);
+    return pack_rgba8_scaled(r * 255.0f, g * 255.0f, b * 255.0f, alpha);
 }
 
 // Running nearest-hit state of the face loop (compute.wgsl:186-202).

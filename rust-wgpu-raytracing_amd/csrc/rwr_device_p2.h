@@ -50,9 +50,15 @@ RWR_DEV f2 div_shared_rcp(f2 n, f2 d, f2 r)
     const f2 q1 = fma2(fma2(-d, q0, n), r, q0);
     return fma2(fma2(-d, q1, n), r, q1);
 }
+RWR_DEV f2 sqrt_fast(f2 x)
+{
+    const f2 y = f2{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
+    const f2 g = x * y, h = 0.5f * y;
+    return fma2(fma2(-g, g, x), h, g);
+}
 RWR_DEV v3 normalize3_fast(v3 a)
 {
-    const f2 len = sqrt2(dot3(a, a));
+    const f2 len = sqrt_fast(dot3(a, a));
     f2 r = f2{__builtin_amdgcn_rcpf(len.x), __builtin_amdgcn_rcpf(len.y)};
     r = fma2(fma2(-len, r, splat(1.0f)), r, r);
     return v3{div_shared_rcp(a.x, len, r), div_shared_rcp(a.y, len, r), div_shared_rcp(a.z, len, r)};
