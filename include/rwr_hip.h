@@ -144,7 +144,7 @@ RWR_API int rwr_ctx_device_info(rwr_context *ctx, char *name, size_t name_cap, i
 
 /* Frames in flight (1..3, default 1).  With n > 1 the context owns n sets of targets and per-frame
  * buffers, each with its own HIP stream, and consecutive rwr_render calls take them in turn, the way a
- * swapchain hands out images (the reference presents through wgpu's surface, lib.rs:1186-1187): the
+ * swapchain hands out images (the reference takes each frame from wgpu's surface and presents it, lib.rs:1013,1227): the
  * next frame's kernels fill the GPU while the previous frame's last waves drain.  rwr_readback and
  * rwr_get_device_targets refer to the frame rendered last and wait for that frame only; a frame's
  * targets stay valid until n further frames have been rendered.  rwr_synchronize, scene changes,
