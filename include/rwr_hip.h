@@ -91,6 +91,14 @@ typedef struct rwr_sphere_buffer_data {
     float radius;
 } rwr_sphere_buffer_data;
 
+/* TriangleBufferData, src/models/triangle/triangle.rs:10-19 — the single-triangle model's uniform
+ * (triangle/compute.wgsl:21-25,50-51).  The reference builds this model type but never dispatches it. */
+typedef struct rwr_triangle_buffer_data {
+    float p0[3]; float pad0;
+    float p1[3]; float pad1;
+    float p2[3]; float pad2;
+} rwr_triangle_buffer_data;
+
 /* InstanceRaw, src/lib.rs:129-134 (computed but never bound by the reference;
  * used here by the instanced configs).  Column-major model matrix; must be rigid
  * (rotation + translation). */
@@ -120,15 +128,20 @@ typedef struct rwr_render_params {
 enum {
     RWR_FLAG_AUX_OUTPUTS = 1u << 0, /* also produce float colour, object id and hit distance planes */
     RWR_FLAG_NO_CULL     = 1u << 1, /* debug: brute-force every face for every pixel (reference loop order) */
-    RWR_FLAG_USE_BVH     = 1u << 2  /* reference frame only: the mesh pass traverses the BVH per ray instead of
+    RWR_FLAG_USE_BVH     = 1u << 2, /* reference frame only: the mesh pass traverses the BVH per ray instead of
                                        walking per-tile candidate lists (better when many small faces share a
                                        tile, e.g. a distant mesh); same result bit for bit */
+    RWR_FLAG_ORTHO_RAYS  = 1u << 3  /* every pass generates its rays with pixelToRay_ortho (defined, never called,
+                                       in all three shaders: triangle_list/compute.wgsl:166-174): origin =
+                                       camera.origin + (5 x_nds, 5 y_nds, 0), direction (0, 0, -1).  Reference
+                                       frame only (spp 1, no bounce, no RWR_FLAG_USE_BVH) */
 };
 
 #define RWR_MAX_SPHERES 8
+#define RWR_MAX_TRIANGLES 8
 
 /* Object id plane encoding (aux output): >= 0 mesh face index
- * (instance * n_faces + face), -1 background, -2-k analytic sphere k. */
+ * (instance * n_faces + face), -1 background, -2-k analytic sphere k, -10-k single triangle k. */
 
 typedef struct rwr_context rwr_context;
 
@@ -187,6 +200,14 @@ RWR_API int rwr_scene_commit(rwr_context *ctx);
 /* Replaces Sphere::new's uniform, one per analytic sphere pass, composited in
  * array order before the mesh (src/lib.rs:532-534, 1106-1173).  n <= RWR_MAX_SPHERES. */
 RWR_API int rwr_scene_set_spheres(rwr_context *ctx, const rwr_sphere_buffer_data *spheres, uint32_t n);
+
+/* Replaces Triangle::new's uniform (src/models/triangle/triangle.rs:37-45), one per single-triangle pass
+ * (triangle/compute.wgsl:153-195).  The reference never dispatches this model, so where its passes sit
+ * in a frame is defined here: after the spheres, before the mesh, in array order.  Its shading is the
+ * sphere's with the face normal as triangleRayIntersect returns it there — flipped towards the ray, NOT
+ * normalised (:120-124,171-187).  n <= RWR_MAX_TRIANGLES; reference frame only (spp 1, no bounce, no
+ * RWR_FLAG_USE_BVH). */
+RWR_API int rwr_scene_set_triangles(rwr_context *ctx, const rwr_triangle_buffer_data *triangles, uint32_t n);
 
 /* Extension: rigid instances of the uploaded mesh (InstanceRaw layout).
  * n = 0 restores the single un-instanced mesh of the reference. */

@@ -163,6 +163,39 @@ def render_frame(cam_inv, screen, spheres, model, want_aux=True) -> dict:
     return {"color": color, "depth": depth, "color_f32": color_f, "obj_id": obj_id, "hit_t": hit_t}
 
 
+TRIANGLE_DTYPE = np.dtype([("p0", "<f4", (3,)), ("pad0", "<f4"), ("p1", "<f4", (3,)), ("pad1", "<f4"),
+                           ("p2", "<f4", (3,)), ("pad2", "<f4")])  # TriangleBufferData, models/triangle/triangle.rs:10-19
+
+
+def make_triangles(tris=()) -> np.ndarray:
+    out = np.zeros(len(tris), dtype=TRIANGLE_DTYPE)
+    for i, (p0, p1, p2) in enumerate(tris):
+        out["p0"][i], out["p1"][i], out["p2"][i] = p0, p1, p2
+    return out
+
+
+def render_frame_ex(cam_inv, screen, spheres, triangles, model, ortho=False) -> dict:
+    """or_render_frame plus the reference's dormant parts: single-triangle passes (after the spheres) and
+    pixelToRay_ortho for every pass."""
+    w, h = int(screen["width"][0]), int(screen["height"][0])
+    color = np.zeros((h, w, 4), np.uint8)
+    depth = np.zeros((h, w), np.float32)
+    color_f = np.zeros((h, w, 4), np.float32)
+    obj_id = np.zeros((h, w), np.int32)
+    hit_t = np.zeros((h, w), np.float32)
+    verts, faces = model["vertices"], model["faces"]
+    tex = np.ascontiguousarray(model["texture"])
+    triangles = np.ascontiguousarray(triangles, dtype=TRIANGLE_DTYPE)
+    rc = lib().or_render_frame_ex(
+        _p(cam_inv), _p(screen), _p(spheres), C.c_uint32(len(spheres)), _p(triangles), C.c_uint32(len(triangles)),
+        _p(verts), C.c_uint32(len(verts)), _p(faces), C.c_uint32(len(faces)),
+        _p(model["material"]), _p(tex), C.c_uint32(tex.shape[1]), C.c_uint32(tex.shape[0]), C.c_uint32(1 if ortho else 0),
+        _p(color), _p(depth), _p(color_f), _p(obj_id), _p(hit_t))
+    if rc != 0:
+        raise MemoryError("or_render_frame_ex")
+    return {"color": color, "depth": depth, "color_f32": color_f, "obj_id": obj_id, "hit_t": hit_t}
+
+
 PARAMS_DTYPE = np.dtype([("spp", "<u4"), ("max_bounces", "<u4"), ("seed", "<u4"), ("flags", "<u4")])
 INSTANCE_DTYPE = np.dtype([("model", "<f4", (4, 4))])
 

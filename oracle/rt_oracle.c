@@ -477,6 +477,150 @@ OR_API int or_render_frame(const OrCameraInvUniform *cam, const OrScreen *screen
 }
 
 
+/* ---------------------------------------------- dormant parts of the reference --
+ * The reference carries, but never dispatches, a single-triangle model
+ * (src/models/triangle/{triangle.rs, compute.wgsl}) and an orthographic ray generator that
+ * every shader defines and none calls (pixelToRay_ortho: triangle_list/compute.wgsl:166-174,
+ * sphere/compute.wgsl:103-111, triangle/compute.wgsl:143-151).  Restated here for SURVEY
+ * §8(f) rank 4.  Where a triangle pass sits in the frame is this project's choice (after the
+ * sphere passes, before the mesh pass): each pass only composites through the depth test. */
+typedef struct { float p0[3], pad0, p1[3], pad1, p2[3], pad2; } OrTriangle; /* triangle.rs:10-19 */
+
+/* pixelToRay_ortho, triangle_list/compute.wgsl:166-174 */
+static inline Ray pixel_to_ray_ortho(const OrCameraInvUniform *cam, const OrScreen *screen, uint32_t x, uint32_t y)
+{
+    float x_nds = 2.0f * ((float)x + 0.5f) / (float)screen->width - 1.0f;
+    float y_nds = 2.0f * ((float)y + 0.5f) / (float)screen->height - 1.0f;
+    Ray r;
+    r.origin = add3(v3_from(cam->origin), V3(x_nds * 5.0f, y_nds * 5.0f, 0.0f));
+    r.direction = V3(0.0f, 0.0f, -1.0f);
+    return r;
+}
+static inline Ray frame_ray(const OrCameraInvUniform *cam, const OrScreen *screen, uint32_t x, uint32_t y, int ortho)
+{
+    return ortho ? pixel_to_ray_ortho(cam, screen, x, y) : pixel_to_ray(cam, screen, x, y, 0.5f, 0.5f);
+}
+
+/* triangleRayIntersect of the single-triangle model, triangle/compute.wgsl:65-125: the same plane +
+ * three inclusive edge tests, but the HitRecord carries N as it is — flipped towards the ray, NOT
+ * normalised (:120-124) — and no barycentrics. */
+static inline HitRecord single_triangle_ray_intersect(v3 p0, v3 p1, v3 p2, Ray ray)
+{
+    v3 v0v1 = sub3(p1, p0);
+    v3 v0v2 = sub3(p2, p0);
+    v3 N = cross3(v0v1, v0v2);
+    float NdotRayDirection = dot3(N, ray.direction);
+    if (fabsf(NdotRayDirection) < kEpsilon) return kNoHit;
+    float d = -dot3(N, p0);
+    float t = -(dot3(N, ray.origin) + d) / NdotRayDirection;
+    if (t < 0.0f) return kNoHit;
+    v3 P = madd3(t, ray.direction, ray.origin);
+    v3 C = cross3(sub3(p1, p0), sub3(P, p0));
+    if (dot3(N, C) < 0.0f) return kNoHit;
+    C = cross3(sub3(p2, p1), sub3(P, p1));
+    if (dot3(N, C) < 0.0f) return kNoHit;
+    C = cross3(sub3(p0, p2), sub3(P, p2));
+    if (dot3(N, C) < 0.0f) return kNoHit;
+    if (NdotRayDirection > 0.0f) N = neg3(N);
+    HitRecord h;
+    h.hit = 1;
+    h.distance = t;
+    h.normal = N;
+    h.barycentric = V3(0, 0, 0);
+    return h;
+}
+
+/* triangle/compute.wgsl:153-195, one invocation per pixel; its shading (:171-187) is the sphere's with
+ * the un-normalised N.  Object id of triangle k: -10 - k. */
+static void triangle_pass(const OrCameraInvUniform *cam, const OrScreen *screen, const OrTriangle *tri, int32_t index,
+                          int ortho, const float *depth_input, float *depth_output, const OrAux *aux)
+{
+    const int W = (int)screen->width, H = (int)screen->height;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            Ray ray = frame_ray(cam, screen, (uint32_t)x, (uint32_t)y, ortho);
+            HitRecord h = single_triangle_ray_intersect(v3_from(tri->p0), v3_from(tri->p1), v3_from(tri->p2), ray);
+            if (!h.hit) continue;
+            size_t idx = (size_t)y * W + x;
+            float current_depth = 1.0f - depth_input[idx];
+            float depth = to_non_linear_depth(h.distance);
+            if (depth >= current_depth) continue;
+            v3 rgb = shade_sphere(&h, ray, NULL);
+            depth_output[idx] = 1.0f - depth;
+            store_pixel(aux, idx, rgb, 2.0f, -10 - index, h.distance);  /* alpha: 1.0 + 1.0, :184-187 */
+        }
+    }
+}
+
+/* or_render_frame with the dormant parts switched on: `triangles` (may be NULL) are single-triangle
+ * passes run after the spheres; `ortho` != 0 makes every pass use pixelToRay_ortho. */
+OR_API int or_render_frame_ex(const OrCameraInvUniform *cam, const OrScreen *screen,
+                              const OrSphere *spheres, uint32_t n_spheres, const OrTriangle *triangles, uint32_t n_triangles,
+                              const OrVertex *verts, uint32_t n_verts, const OrFace *faces, uint32_t n_faces,
+                              const OrMaterial *material, const uint8_t *tex_rgba8, uint32_t tex_w, uint32_t tex_h,
+                              uint32_t ortho,
+                              uint8_t *color_u8, float *depth_out, float *color_f32, int32_t *obj_id, float *hit_t)
+{
+    size_t n = (size_t)screen->width * screen->height;
+    float *depth_in = (float *)calloc(n, sizeof(float));
+    if (!depth_in) return -1;
+    memset(depth_out, 0, n * sizeof(float));
+    if (color_u8) memset(color_u8, 0, n * 4);
+    if (color_f32) memset(color_f32, 0, n * 4 * sizeof(float));
+    if (obj_id) for (size_t i = 0; i < n; i++) obj_id[i] = -1;
+    if (hit_t) memset(hit_t, 0, n * sizeof(float));
+    OrAux aux = {color_u8, color_f32, obj_id, hit_t};
+    const int W = (int)screen->width, H = (int)screen->height;
+    for (uint32_t s = 0; s < n_spheres; s++) {
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int y = 0; y < H; y++) {
+            for (int x = 0; x < W; x++) {   /* or_sphere_pass with the selectable ray */
+                Ray ray = frame_ray(cam, screen, (uint32_t)x, (uint32_t)y, (int)ortho);
+                HitRecord h = sphere_ray_intersect(v3_from(spheres[s].center), spheres[s].radius, ray);
+                if (!h.hit) continue;
+                size_t idx = (size_t)y * W + x;
+                float current_depth = 1.0f - depth_in[idx];
+                float depth = to_non_linear_depth(h.distance);
+                if (depth >= current_depth) continue;
+                v3 rgb = shade_sphere(&h, ray, NULL);
+                depth_out[idx] = 1.0f - depth;
+                store_pixel(&aux, idx, rgb, 2.0f, -2 - (int32_t)s, h.distance);
+            }
+        }
+        memcpy(depth_in, depth_out, n * sizeof(float));
+    }
+    for (uint32_t k = 0; k < n_triangles; k++) {
+        triangle_pass(cam, screen, &triangles[k], (int32_t)k, (int)ortho, depth_in, depth_out, &aux);
+        memcpy(depth_in, depth_out, n * sizeof(float));
+    }
+    if (n_faces > 0) {
+        Mesh m;
+        m.verts = verts; m.n_verts = n_verts; m.faces = faces; m.n_faces = n_faces; m.material = material;
+        m.tex.rgba = tex_rgba8; m.tex.w = tex_w; m.tex.h = tex_h;
+        m.face_material = NULL; m.n_base_faces = n_faces; m.materials = NULL; m.texs = NULL;
+        build_srgb_lut(m.tex.lut);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int y = 0; y < H; y++) {
+            for (int x = 0; x < W; x++) {   /* or_mesh_pass with the selectable ray */
+                Ray ray = frame_ray(cam, screen, (uint32_t)x, (uint32_t)y, (int)ortho);
+                int i_min;
+                HitRecord h = mesh_nearest(&m, ray, &i_min);
+                if (!h.hit) continue;
+                size_t idx = (size_t)y * W + x;
+                float current_depth = 1.0f - depth_in[idx];
+                float depth = to_non_linear_depth(h.distance);
+                if (depth >= current_depth) continue;
+                v3 rgb = shade_mesh(&m, (uint32_t)i_min, &h, ray, NULL);
+                depth_out[idx] = 1.0f - depth;
+                store_pixel(&aux, idx, rgb, 2.0f, i_min, h.distance);
+            }
+        }
+    }
+    free(depth_in);
+    return 0;
+}
+
 /* ================================================================ EXTENSION ==
  * Multi-sample / one-bounce / instanced integrator (BASELINE.json configs 3-5).
  * The reference has none of this: the definition below is this

@@ -31,6 +31,8 @@ MATERIAL_DTYPE = np.dtype([("ambient", "<f4", (3,)), ("pad0", "<f4"), ("diffuse"
                            ("specular", "<f4", (3,)), ("pad2", "<f4")])
 SPHERE_DTYPE = np.dtype([("center", "<f4", (3,)), ("radius", "<f4")])
 INSTANCE_DTYPE = np.dtype([("model", "<f4", (4, 4))])
+TRIANGLE_DTYPE = np.dtype([("p0", "<f4", (3,)), ("pad0", "<f4"), ("p1", "<f4", (3,)), ("pad1", "<f4"),
+                           ("p2", "<f4", (3,)), ("pad2", "<f4")])  # rwr_triangle_buffer_data, 48 B
 CAMERA_DTYPE = np.dtype([("eye", "<f4", (3,)), ("target", "<f4", (3,)), ("up", "<f4", (3,)),
                          ("aspect", "<f4"), ("fovy", "<f4"), ("znear", "<f4"), ("zfar", "<f4")])
 PARAMS_DTYPE = np.dtype([("spp", "<u4"), ("max_bounces", "<u4"), ("seed", "<u4"), ("flags", "<u4")])
@@ -39,6 +41,7 @@ assert (CAMERA_INV_DTYPE.itemsize, VERTEX_DTYPE.itemsize, FACE_DTYPE.itemsize, M
 
 FLAG_AUX_OUTPUTS, FLAG_NO_CULL, FLAG_USE_BVH = 1, 2, 4
 # internal debug flags (csrc/rwr_internal.h, not part of include/rwr_hip.h)
+FLAG_ORTHO_RAYS = 1 << 3
 FLAG_DEBUG_COUNTS, FLAG_ONE_PIXEL_PER_LANE = 1 << 16, 1 << 17
 KEY_FORWARD, KEY_BACKWARD, KEY_LEFT, KEY_RIGHT, KEY_UP, KEY_DOWN = 1, 2, 4, 8, 16, 32
 OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NOT_READY, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
@@ -95,7 +98,7 @@ def lib() -> C.CDLL:
         "rwr_scene_clear": [vp], "rwr_scene_add_mesh": [vp, vp, u32, vp, u32, vp, vp, u32, u32], "rwr_scene_commit": [vp],
         "rwr_model_part_count": [vp, vp], "rwr_model_part": [vp, u32, vp, vp, vp, vp, vp, vp, vp, vp],
         "rwr_scene_upload_model_all": [vp, vp],
-        "rwr_scene_set_spheres": [vp, vp, u32], "rwr_scene_set_instances": [vp, vp, u32],
+        "rwr_scene_set_spheres": [vp, vp, u32], "rwr_scene_set_triangles": [vp, vp, u32], "rwr_scene_set_instances": [vp, vp, u32],
         "rwr_resize": [vp, vp], "rwr_render": [vp, vp, vp], "rwr_render_rows": [vp, vp, vp, u32, u32],
         "rwr_synchronize": [vp], "rwr_readback": [vp, vp, vp, vp, vp, vp], "rwr_get_device_targets": [vp, vp, vp],
         "rwr_timer_begin": [vp], "rwr_timer_end": [vp, vp], "rwr_last_render_stats": [vp, vp, vp],
@@ -160,6 +163,13 @@ def make_spheres(spec=REFERENCE_SPHERES) -> np.ndarray:
     for i, (c, r) in enumerate(spec):
         s[i]["center"], s[i]["radius"] = c, r
     return s
+
+
+def make_triangles(spec=()) -> np.ndarray:
+    t = np.zeros(len(spec), dtype=TRIANGLE_DTYPE)
+    for i, (p0, p1, p2) in enumerate(spec):
+        t[i]["p0"], t[i]["p1"], t[i]["p2"] = p0, p1, p2
+    return t
 
 
 def make_params(spp=1, max_bounces=0, seed=0, flags=0) -> np.ndarray:
@@ -306,6 +316,11 @@ class Context:
     def set_spheres(self, spheres):
         spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
         _check(lib().rwr_scene_set_spheres(self._h, _p(spheres) if len(spheres) else None, len(spheres)))
+
+    def set_triangles(self, triangles):
+        """Single-triangle passes (the reference's dormant models/triangle), after the spheres."""
+        triangles = np.ascontiguousarray(triangles, dtype=TRIANGLE_DTYPE)
+        _check(lib().rwr_scene_set_triangles(self._h, _p(triangles) if len(triangles) else None, len(triangles)))
 
     def set_instances(self, instances):
         n = 0 if instances is None else len(instances)

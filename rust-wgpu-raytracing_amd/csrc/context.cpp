@@ -134,6 +134,8 @@ struct rwr_context {
     bool tris_dirty = false;
     rwr_sphere_buffer_data spheres[RWR_MAX_SPHERES]{};
     uint32_t n_spheres = 0;
+    rwr_triangle_buffer_data triangles[RWR_MAX_TRIANGLES]{};
+    uint32_t n_triangles = 0;
 
     // targets
     rwr_screen screen{0, 0};
@@ -547,6 +549,16 @@ int rwr_scene_set_spheres(rwr_context *ctx, const rwr_sphere_buffer_data *sphere
     return RWR_OK;
 }
 
+int rwr_scene_set_triangles(rwr_context *ctx, const rwr_triangle_buffer_data *triangles, uint32_t n)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (n > RWR_MAX_TRIANGLES) return set_error(RWR_ERR_INVALID_ARGUMENT, "at most %d single triangles", RWR_MAX_TRIANGLES);
+    if (n && !triangles) return set_error(RWR_ERR_INVALID_ARGUMENT, "triangles is NULL with n = %u", n);
+    for (uint32_t i = 0; i < n; i++) ctx->triangles[i] = triangles[i];   // passed by value with every launch
+    ctx->n_triangles = n;
+    return RWR_OK;
+}
+
 int rwr_scene_set_instances(rwr_context *ctx, const rwr_instance_raw *instances, uint32_t n)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
@@ -599,6 +611,10 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         return set_error(RWR_ERR_UNSUPPORTED, "RWR_FLAG_USE_BVH applies to the reference frame (spp 1, no bounce); bounce rays always use the BVH");
     if (rp.spp > 4096) return set_error(RWR_ERR_INVALID_ARGUMENT, "spp must be <= 4096");
     const bool wavefront = rp.spp != 1 || rp.max_bounces != 0;
+    // the reference's dormant parts (single-triangle passes, orthographic rays) have their own plain kernel
+    const bool dormant = ctx->n_triangles != 0 || (rp.flags & RWR_FLAG_ORTHO_RAYS) != 0;
+    if (dormant && (wavefront || (rp.flags & RWR_FLAG_USE_BVH)))
+        return set_error(RWR_ERR_UNSUPPORTED, "single-triangle passes and RWR_FLAG_ORTHO_RAYS apply to the reference frame (spp 1, no bounce, no RWR_FLAG_USE_BVH)");
 
     DeviceGuard g(ctx->device);
     const size_t n = (size_t)ctx->screen.width * ctx->screen.height;
@@ -693,10 +709,16 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         }
     }
     // the two-pixel frame kernel is timed by its own dispatch timestamps; everything else by stream events
-    const bool dispatch_timed = time_this && !wavefront && !(rp.flags & RWR_FLAG_USE_BVH) &&
+    const bool dispatch_timed = time_this && !wavefront && !dormant && !(rp.flags & RWR_FLAG_USE_BVH) &&
                                 !((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel);
     if (time_this && !dispatch_timed) RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs], stream));
-    if (!wavefront && (rp.flags & RWR_FLAG_USE_BVH)) {
+    if (dormant) {
+        SingleTriangles st{};
+        st.n = ctx->n_triangles;
+        for (uint32_t i = 0; i < ctx->n_triangles; i++) st.t[i] = ctx->triangles[i];
+        RWR_HIP_CHECK(launch_primary_dormant(stream, fp, st, ctx->d_tris.ptr, ctx->d_shade.ptr, tex0, tg));
+        ctx->last_spp = 0;
+    } else if (!wavefront && (rp.flags & RWR_FLAG_USE_BVH)) {
         const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
         RWR_HIP_CHECK(launch_primary_bvh(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh_p, tex0, tg));
         ctx->last_spp = 0;

@@ -202,6 +202,15 @@ struct FrameSetupOut {
     float4 *ray_row;   // ray_rows
     uint32_t ray_pairs, ray_rows;
 };
+// kernels_dormant.hip: frames with single-triangle passes or orthographic rays (brute force, one pixel per lane)
+struct SingleTriangles {  // the single-triangle passes of a frame (kept out of FrameParams: only this kernel reads them)
+    uint32_t n;
+    uint32_t pad[3];
+    rwr_triangle_buffer_data t[RWR_MAX_TRIANGLES];
+};
+hipError_t launch_primary_dormant(hipStream_t s, const FrameParams &fp, const SingleTriangles &st, const TriRecord *tris,
+                                  const ShadeRec *shade, const float4 *tex, const Targets &tg);
+
 // kernels_selftest.hip: out[0..3] += depth inputs compared, mismatches, normalize inputs compared, mismatches
 hipError_t launch_selftest_exact_math(hipStream_t s, unsigned long long *d_out4, uint32_t normalize_count, uint32_t seed);
 
