@@ -151,7 +151,7 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Shad
     uint32_t n_tested = 0;  // wave-uniform
     ShadeRec last_shade = {};  // of the face tested last (scalar registers)
     {
-        // Each wave culls for its own 16x8 tile, 64 faces at a time, one per lane (rwr_cull.h), and walks
+        // Each wave culls for its own tile, 64 faces at a time, one per lane (rwr_cull.h), and walks
         // the survivors in ascending face order: no LDS, no barrier.  The next 64 records are requested
         // before the exact tests of the current ones.
         const TileRect tile_rect = {tx0, ty0, tx0 + kTileWf, ty0 + kTileHf};
