@@ -114,10 +114,11 @@ def main() -> int:
                     help="initialise torch.distributed (RCCL) and run the gather path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    # defaults: 16 us frames need ~1000 of them before the clocks and caches have settled (50: 4 % slower)
     if args.steps is None:
-        args.steps = cfg.get("steps", 2000)
+        args.steps = cfg.get("steps", 4000)
     if args.warmup is None:
-        args.warmup = cfg.get("warmup", 50)
+        args.warmup = cfg.get("warmup", 1000)
 
     import torch
     import __graft_entry__ as graft
@@ -164,7 +165,8 @@ def main() -> int:
     stream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    ctx.set_stream(stream.cuda_stream)
+    if use_dist:
+        ctx.set_stream(stream.cuda_stream)   # the RCCL gather must follow the render in stream order
 
     # Frames in flight: like a swapchain, the context owns two sets of targets and alternates between
     # them, so one frame's kernel ramps up while the previous frame's last waves drain (at 1080p about
@@ -205,7 +207,7 @@ def main() -> int:
 
     # dominant-kernel duration: HIP events around that kernel alone, on its launch stream, for a
     # sample of the frames INSIDE the timed region (every 16th frame at most 256 brackets)
-    ctx.set_kernel_timing(max(1, args.steps // 128))
+    ctx.set_kernel_timing(int(os.environ.get("RWR_BENCH_TIMING_EVERY", max(1, args.steps // 128))))
     # timed region: exactly K steps; HIP events on the launch stream for the whole region
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -2,6 +2,9 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
+if "--torch" in sys.argv:   # as bench.py runs: torch initialised, a torch stream current
+    import torch
+    torch.cuda.set_device(0); _s = torch.cuda.Stream(); torch.cuda.set_stream(_s); torch.zeros(1, device="cuda")
 r = g.load_package()
 suz = r.load_model_compute("suzanne_lowpoly.obj")
 ci = r.camera_build_inv_uniform(r.make_camera(eye=(0, 0, 0), aspect=16 / 9))
