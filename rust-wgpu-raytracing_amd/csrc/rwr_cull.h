@@ -105,8 +105,10 @@ RWR_DEV bool rect_culls(const FrameTri &T, const TileRect &r)
     const float me[3] = {T.me0, T.me1, T.me2};
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        // d_i is affine, so its maximum over the rectangle separates in x and y
-        const float dmax = T.ea[i] + fmaxf(r.x0 * T.ex[i], r.x1 * T.ex[i]) + fmaxf(r.y0 * T.ey[i], r.y1 * T.ey[i]);
+        // d_i is affine, so its maximum over the rectangle is at the corner its gradient points to
+        // (a NaN anywhere makes the comparison false: the face is kept)
+        const float xs = T.ex[i] >= 0.0f ? r.x1 : r.x0, ys = T.ey[i] >= 0.0f ? r.y1 : r.y0;
+        const float dmax = ffma(xs, T.ex[i], ffma(ys, T.ey[i], T.ea[i]));
         c |= dmax < -me[i];
     }
     return c;

@@ -1,4 +1,4 @@
-"""Debug: candidate-face statistics of the two-level cull (needs a GPU)."""
+"""Debug: candidate-face statistics of the per-wave cull of the frame kernel (needs a GPU)."""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
@@ -12,6 +12,6 @@ for scene, eye, (w, h) in [("suzanne_lowpoly.obj", (0, 0, 0), (1920, 1080)), ("s
         ci = r.camera_build_inv_uniform(r.make_camera(eye=eye, aspect=w / h))
         ctx.render(ci, r.make_params(flags=r.FLAG_AUX_OUTPUTS | DEBUG_COUNTS))
         o = ctx.readback(aux=True)
-    listed = o["obj_id"][::8, ::32].astype(float); tested = o["hit_t"][::8, ::8]
-    print(scene, eye, "faces", len(m["faces"]), "block list mean/max", listed.mean(), listed.max(),
-          "wave tested mean/max", tested.mean(), tested.max())
+    listed = o["obj_id"][::4, ::32].astype(float); tested = o["hit_t"][::4, ::32]   # one sample per 32x4 tile
+    print(scene, eye, "faces", len(m["faces"]), "faces past the tile cull per wave mean/max", listed.mean(), listed.max(),
+          "exact tests per wave mean/max", tested.mean(), tested.max())
