@@ -14,8 +14,9 @@
  *     for the calling thread's last failure is rwr_last_error_string().
  *     Nothing aborts or panics (the reference unwrap()s: lib.rs:275,284,303,566).
  *   - one context = one GPU = one caller thread (the reference's State is !Send,
- *     lib.rs:256).  Rendering is asynchronous on the context's HIP stream;
- *     rwr_readback()/rwr_synchronize() wait for it.
+ *     lib.rs:256).  Rendering is asynchronous on the context's HIP stream(s);
+ *     rwr_readback() waits for the frame rendered last, rwr_synchronize() for
+ *     every frame in flight (rwr_ctx_set_frames_in_flight).
  *   - caller owns host arrays; uploads copy; the context owns device memory
  *     until rwr_ctx_destroy().
  *   - all PODs are layout-identical to the reference's #[repr(C)] structs.
@@ -239,11 +240,14 @@ RWR_API int rwr_synchronize(rwr_context *ctx);
 RWR_API int rwr_readback(rwr_context *ctx, uint8_t *rgba8, float *depth,
                          float *rgba_f32, int32_t *obj_id, float *hit_t);
 
-/* Device addresses of the targets, for zero-copy consumers (RCCL gather of
- * finished bands, presentation).  Valid until the next rwr_resize. */
+/* Device addresses of the targets of the frame rendered last, for zero-copy consumers
+ * (RCCL gather of finished bands, presentation).  They stay the same from frame to frame
+ * with one frame in flight (the default) and alternate between the target sets otherwise;
+ * valid until the next rwr_resize / rwr_ctx_set_frames_in_flight. */
 RWR_API int rwr_get_device_targets(rwr_context *ctx, void **d_rgba8, void **d_depth);
 
-/* hipEvent timing on the stream the kernels are launched on. */
+/* hipEvent timing on the stream(s) the kernels are launched on: rwr_timer_begin waits until nothing
+ * is in flight and records; rwr_timer_end joins every frame in flight into the end event. */
 RWR_API int rwr_timer_begin(rwr_context *ctx);
 RWR_API int rwr_timer_end(rwr_context *ctx, float *elapsed_ms); /* synchronises on the end event */
 
