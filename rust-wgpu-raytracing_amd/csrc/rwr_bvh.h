@@ -57,15 +57,25 @@ RWR_DEV void intersect_and_select_any_order(const TriRecord &T, uint32_t idx, f3
 }
 
 // Ray constants of the slab test:  t = b * inv - O * inv  (one FMA per plane; conservative
-// code may fuse).  +-inf for axis-parallel rays is fine, see bvh_inner_step.
-struct SlabRay { float ix, iy, iz, ox, oy, oz; };
+// code may fuse).  +-inf for axis-parallel rays is fine, see bvh_inner_step.  (nx, ny, nz): which of
+// a node's six float4 planes {min x, min y, min z, max x, max y, max z} (bvh.hpp BvhNode4) is the
+// NEAR one on each axis for this ray — the sign of the reciprocal picks it, so a node visit loads
+// near and far planes directly instead of ordering them with six min/max per box.
+struct SlabRay { float ix, iy, iz, ox, oy, oz; uint32_t nx, ny, nz; };
 RWR_DEV SlabRay make_slab_ray(f3 O, f3 D)
 {
     SlabRay r;
     r.ix = 1.0f / D.x; r.iy = 1.0f / D.y; r.iz = 1.0f / D.z;
     r.ox = -O.x * r.ix; r.oy = -O.y * r.iy; r.oz = -O.z * r.iz;
+    r.nx = 3u * (__float_as_uint(r.ix) >> 31);        // sign bit, so that 1 / -0 = -inf counts as negative
+    r.ny = 3u * (__float_as_uint(r.iy) >> 31) + 1u;
+    r.nz = 3u * (__float_as_uint(r.iz) >> 31) + 2u;
     return r;
 }
+static_assert(offsetof(BvhNode4, bmin_y) == 16 && offsetof(BvhNode4, bmin_z) == 32 && offsetof(BvhNode4, bmax_x) == 48 &&
+              offsetof(BvhNode4, bmax_y) == 64 && offsetof(BvhNode4, bmax_z) == 80, "plane order the traversal indexes by");
+
+RWR_DEV float f4at(const float4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
 // One inner-node visit of one lane: tests the four child boxes, continues with the nearest
 // survivor (returned in `cur`) and pushes the others; pops when nothing survives.  Returns
@@ -81,15 +91,19 @@ RWR_DEV bool bvh_inner_step(NodePtr nodes, const SlabRay &sr, float tbest, uint3
                             uint32_t stride)
 {
     uint32_t key[4], child[4];
+    const auto *planes = reinterpret_cast<const float4 *>(&nodes[cur].bmin_x[0]);  // keeps NodePtr's address space
+    const float4 nearx = planes[sr.nx], farx = planes[3u - sr.nx];
+    const float4 neary = planes[sr.ny], fary = planes[5u - sr.ny];
+    const float4 nearz = planes[sr.nz], farz = planes[7u - sr.nz];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         child[i] = nodes[cur].child[i];
         // NaN (0 * inf: origin exactly on a slab plane of an axis-parallel ray) is ignored by min/max
-        const float x0 = __builtin_fmaf(nodes[cur].bmin_x[i], sr.ix, sr.ox), x1 = __builtin_fmaf(nodes[cur].bmax_x[i], sr.ix, sr.ox);
-        const float y0 = __builtin_fmaf(nodes[cur].bmin_y[i], sr.iy, sr.oy), y1 = __builtin_fmaf(nodes[cur].bmax_y[i], sr.iy, sr.oy);
-        const float z0 = __builtin_fmaf(nodes[cur].bmin_z[i], sr.iz, sr.oz), z1 = __builtin_fmaf(nodes[cur].bmax_z[i], sr.iz, sr.oz);
-        const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-        const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const float x0 = __builtin_fmaf(f4at(nearx, i), sr.ix, sr.ox), x1 = __builtin_fmaf(f4at(farx, i), sr.ix, sr.ox);
+        const float y0 = __builtin_fmaf(f4at(neary, i), sr.iy, sr.oy), y1 = __builtin_fmaf(f4at(fary, i), sr.iy, sr.oy);
+        const float z0 = __builtin_fmaf(f4at(nearz, i), sr.iz, sr.oz), z1 = __builtin_fmaf(f4at(farz, i), sr.iz, sr.oz);
+        const float tnear = fmaxf(fmaxf(x0, y0), z0);
+        const float tfar = fminf(fminf(x1, y1), z1);
         // conservative: relative slack on both distances; equal-distance nodes are kept (<=)
         const float lo = fmaxf(tnear - 4e-5f * fabsf(tnear), 0.0f);
         const float hi = fminf(tfar + 4e-5f * fabsf(tfar) + 1e-30f, tbest);
