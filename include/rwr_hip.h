@@ -131,7 +131,9 @@ enum {
     RWR_FLAG_NO_CULL     = 1u << 1, /* debug: brute-force every face for every pixel (reference loop order) */
     RWR_FLAG_USE_BVH     = 1u << 2, /* reference frame only: the mesh pass traverses the BVH per ray instead of
                                        walking per-tile candidate lists (better when many small faces share a
-                                       tile, e.g. a distant mesh); same result bit for bit */
+                                       tile, e.g. a distant mesh); same result bit for bit.  The context picks
+                                       this kernel by itself when a scene of more than 256 faces projects to
+                                       faces far smaller than a tile */
     RWR_FLAG_ORTHO_RAYS  = 1u << 3  /* every pass generates its rays with pixelToRay_ortho (defined, never called,
                                        in all three shaders: triangle_list/compute.wgsl:166-174): origin =
                                        camera.origin + (5 x_nds, 5 y_nds, 0), direction (0, 0, -1).  Reference

@@ -111,6 +111,8 @@ struct rwr_context {
     DeviceBuffer<BvhNode4> d_bvh_nodes;
     DeviceBuffer<uint32_t> d_bvh_leaf_faces;
     uint32_t bvh_n_nodes = 0, bvh_depth = 0;
+    float aabb_lo[3] = {0, 0, 0}, aabb_hi[3] = {0, 0, 0};   // of the (flattened) world-space faces
+    float auto_bvh_face_px = 150.0f;   // tunable: RWR_AUTO_BVH_FACE_PX (0 = never pick the BVH kernel by itself)
     // wavefront integrator state
     DeviceBuffer<float4> d_accum, d_q0, d_q1;
     DeviceBuffer<float2> d_q2;
@@ -255,6 +257,38 @@ void compute_cull_consts(const rwr_camera_inv_uniform &cam, uint32_t width, uint
     cc.enabled = (ok && cc.vxa != 0.0f && cc.vya != 0.0f) ? 1u : 0u;
 }
 
+// Average projected area, in pixels, of a face of the mesh as this camera sees it: the area of the
+// screen rectangle of the mesh's bounding box (clipped to the frame) over half the face count.
+// +inf when any box corner is behind (or beside) the camera — the camera is in or near the mesh and
+// its faces are large on screen — or when the question is meaningless.  The frame kernel walks, per
+// 32x4-pixel tile, every face that may touch the tile, one after the other; when faces are much smaller
+// than a tile (a distant or finely tessellated mesh) the per-ray BVH traversal of k_primary_bvh is
+// faster (tools/dense_probe.py: cube.obj, 428 faces, from 8 units away and beyond — up to 2x) and gives
+// the same frame bit for bit, so the context switches to it for binned scenes (more than 256 faces; a
+// smaller mesh bounds the walk by itself).
+double mean_face_pixels(const CullConsts &cc, const float lo[3], const float hi[3], uint32_t n_tris, uint32_t width,
+                        uint32_t height)
+{
+    if (!cc.enabled || n_tris == 0) return INFINITY;
+    double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    for (int c = 0; c < 8; c++) {
+        double q[3], vx = 0.0, vy = 0.0, ux = 0.0, uy = 0.0;
+        for (int k = 0; k < 3; k++) {
+            q[k] = (double)((c >> k & 1) ? hi[k] : lo[k]) - (double)cc.origin[k];
+            vx += cc.Vx[k] * q[k]; vy += cc.Vy[k] * q[k]; ux += cc.Ux[k] * q[k]; uy += cc.Uy[k] * q[k];
+        }
+        // depth along the view direction of this corner (see compute_sphere_rects); must be clearly in front
+        if (!(vx / cc.vxa > 1e-6) || !(vy / cc.vya > 1e-6)) return INFINITY;
+        const double x = -ux / vx, y = -uy / vy;
+        if (!std::isfinite(x) || !std::isfinite(y)) return INFINITY;
+        x0 = std::fmin(x0, x); x1 = std::fmax(x1, x); y0 = std::fmin(y0, y); y1 = std::fmax(y1, y);
+    }
+    x0 = std::fmax(x0, 0.0); y0 = std::fmax(y0, 0.0);
+    x1 = std::fmin(x1, (double)width); y1 = std::fmin(y1, (double)height);
+    if (!(x1 > x0) || !(y1 > y0)) return INFINITY;   // off screen: nothing to trace either way
+    return (x1 - x0) * (y1 - y0) / (0.5 * (double)n_tris);
+}
+
 // Conservative pixel-space bounds of each analytic sphere's silhouette, so that
 // tiles which cannot see a sphere skip its intersection test (the skipped test
 // would have returned "no hit").  The sphere touches pixel column x iff its
@@ -319,6 +353,12 @@ int rebuild_tris(rwr_context *ctx)
         std::memcpy(&corners[9 * (size_t)i + 3], host_cull[i].p1, 12);
         std::memcpy(&corners[9 * (size_t)i + 6], host_cull[i].p2, 12);
     }
+    for (int k = 0; k < 3; k++) { ctx->aabb_lo[k] = INFINITY; ctx->aabb_hi[k] = -INFINITY; }
+    for (size_t v = 0; v < (size_t)total * 3; v++)
+        for (int k = 0; k < 3; k++) {
+            ctx->aabb_lo[k] = std::fmin(ctx->aabb_lo[k], corners[3 * v + k]);
+            ctx->aabb_hi[k] = std::fmax(ctx->aabb_hi[k], corners[3 * v + k]);
+        }
     uint32_t max_leaf = kBvhMaxLeafDefault;
     if (const char *e = std::getenv("RWR_BVH_LEAF")) max_leaf = (uint32_t)std::strtoul(e, nullptr, 10);  // tuning knob
     const Bvh bvh = build_bvh(corners.data(), total, max_leaf);
@@ -380,6 +420,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     ctx->slots[0].stream = ctx->stream;
     if (const char *e2 = std::getenv("RWR_WAVE_CULL_MIN")) ctx->wave_cull_min = (uint32_t)std::strtoul(e2, nullptr, 10);
     if (const char *e4 = std::getenv("RWR_ONE_PIXEL_PER_LANE")) ctx->force_one_pixel = std::atoi(e4) != 0;
+    if (const char *e5 = std::getenv("RWR_AUTO_BVH_FACE_PX")) ctx->auto_bvh_face_px = (float)std::atof(e5);
     if (const char *e3 = std::getenv("RWR_BIN_MIN_FACES")) ctx->bin_min_faces = (uint32_t)std::strtoul(e3, nullptr, 10);
     *out_ctx = ctx;
     return RWR_OK;
@@ -709,7 +750,12 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         }
     }
     // the two-pixel frame kernel is timed by its own dispatch timestamps; everything else by stream events
-    const bool dispatch_timed = time_this && !wavefront && !dormant && !(rp.flags & RWR_FLAG_USE_BVH) &&
+    // faces much smaller than a tile: the per-ray BVH kernel is the faster way to the same frame
+    const bool auto_bvh = !wavefront && !dormant && !(rp.flags & (RWR_FLAG_NO_CULL | RWR_FLAG_ONE_PIXEL_PER_LANE)) &&
+                          !ctx->force_one_pixel && ctx->n_tris > ctx->bin_min_faces && ctx->auto_bvh_face_px > 0.0f &&
+                          mean_face_pixels(cc, ctx->aabb_lo, ctx->aabb_hi, ctx->n_tris, ctx->screen.width, ctx->screen.height) <
+                              (double)ctx->auto_bvh_face_px;
+    const bool dispatch_timed = time_this && !wavefront && !dormant && !auto_bvh && !(rp.flags & RWR_FLAG_USE_BVH) &&
                                 !((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel);
     if (time_this && !dispatch_timed) RWR_HIP_CHECK(hipEventRecord(ctx->timing_events[2 * ctx->timing_pairs], stream));
     if (dormant) {
@@ -718,7 +764,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         for (uint32_t i = 0; i < ctx->n_triangles; i++) st.t[i] = ctx->triangles[i];
         RWR_HIP_CHECK(launch_primary_dormant(stream, fp, st, ctx->d_tris.ptr, ctx->d_shade.ptr, tex0, tg));
         ctx->last_spp = 0;
-    } else if (!wavefront && (rp.flags & RWR_FLAG_USE_BVH)) {
+    } else if (!wavefront && ((rp.flags & RWR_FLAG_USE_BVH) || auto_bvh)) {
         const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
         RWR_HIP_CHECK(launch_primary_bvh(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh_p, tex0, tg));
         ctx->last_spp = 0;

@@ -44,3 +44,24 @@ def test_frames_in_flight_give_the_same_frames(rwr, gpu_ctx, suzanne):
         gpu_ctx.set_frames_in_flight(0)
     with pytest.raises(rwr.RwrError):
         gpu_ctx.set_frames_in_flight(4)
+
+
+@pytest.mark.gpu
+def test_auto_bvh_for_small_projected_faces_is_invisible(rwr, orc, gpu_ctx, cube):
+    """A binned mesh whose faces project far below a tile (cube.obj from 20 units away) is rendered by the
+    per-ray BVH kernel without being asked to; the frame must be the one the tile kernels produce."""
+    w, h = 320, 200
+    cam = rwr.camera_build_inv_uniform(rwr.make_camera(eye=(0.4, 0.3, 20.0), target=(0, 0, -1), aspect=w / h))
+    gpu_ctx.upload_model(cube); gpu_ctx.set_instances(None); gpu_ctx.set_spheres(rwr.make_spheres(rwr.REFERENCE_SPHERES))
+    gpu_ctx.resize(w, h)
+    frames = []
+    for flags in (0, rwr.FLAG_ONE_PIXEL_PER_LANE, rwr.FLAG_USE_BVH, rwr.FLAG_NO_CULL):
+        gpu_ctx.render(cam, rwr.make_params(flags=flags | rwr.FLAG_AUX_OUTPUTS))
+        frames.append(gpu_ctx.readback(aux=True))
+    for f in frames[1:]:
+        for k in ("obj_id", "hit_t", "depth", "color", "color_f32"):
+            assert np.array_equal(frames[0][k], f[k]), k
+    want = orc.render_frame(cam.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h),
+                            rwr.make_spheres(rwr.REFERENCE_SPHERES).view(orc.SPHERE_DTYPE), cube)
+    assert np.array_equal(frames[0]["obj_id"], want["obj_id"]) and (frames[0]["obj_id"] >= 0).any()
+    assert np.array_equal(frames[0]["depth"].view(np.uint32), want["depth"].view(np.uint32))
