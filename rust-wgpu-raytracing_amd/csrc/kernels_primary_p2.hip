@@ -84,15 +84,18 @@ RWR_DEV void shade_mesh_pair(const FrameParams &p, const ShadeRec *__restrict__ 
 #endif
 template <bool AUX, bool CULL>
 __global__ void __launch_bounds__(256, AUX ? 4 : RWR_P2_OCC)
-k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
-             const FrameTri *__restrict__ ftris, const float4 *__restrict__ tex,
-             const Targets tg)
+// (the first seven arguments repeat FrameParams fields: they are what a wave needs first, and the Makefile
+// has their 10 dwords preloaded into SGPRs)
+k_primary_p2(const FrameTri *__restrict__ ftris, const float4 *__restrict__ ray_colp, const float4 *__restrict__ ray_row,
+             uint32_t n_tris, uint32_t row_begin, uint32_t bins_enabled, uint32_t pad0,
+             const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
+             const float4 *__restrict__ tex, const Targets tg)
 {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t blk_x0 = blockIdx.x * 64u;
 #if RWR_P2_TILE_32x4
     const uint32_t tile_x0 = blk_x0 + (wave & 1u) * 32u;
-    const uint32_t tile_y0 = p.row_begin + blockIdx.y * 8u + (wave >> 1) * 4u;
+    const uint32_t tile_y0 = row_begin + blockIdx.y * 8u + (wave >> 1) * 4u;
     const uint32_t px0 = tile_x0 + 2u * (lane & 15u), py = tile_y0 + (lane >> 4);
     constexpr float kTileWf = 32.0f, kTileHf = 4.0f;
 #else
@@ -104,10 +107,10 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Shad
 
     // -- candidate faces of this wave's tile: the first 64 culling records are requested before anything
     // else, so that their latency hides behind the ray generation ------------------------------
-    uint32_t n_src = p.n_tris;
+    uint32_t n_src = n_tris;
     const uint32_t *__restrict__ src = nullptr;
-    if (CULL && p.bins.enabled) {
-        const uint32_t bin = ((tile_y0 - p.row_begin) / kBinH) * p.bins.bins_x + blk_x0 / kBinW;
+    if (CULL && bins_enabled) {
+        const uint32_t bin = ((tile_y0 - row_begin) / kBinH) * p.bins.bins_x + blk_x0 / kBinW;
         n_src = p.bins.counts[bin];
         src = p.bins.lists + (size_t)bin * p.bins.cap;
     }
@@ -118,7 +121,7 @@ k_primary_p2(const FrameParams p, const TriRecord *__restrict__ tris, const Shad
     if (CULL && valid) cur = ftris[face];
 
     const f3 O = ld3(p.cam.origin);
-    const v3 D = pixel_pair_ray_dir_tab(p.cam, p.ray_colp, p.ray_row, px0, py);
+    const v3 D = pixel_pair_ray_dir_tab(p.cam, ray_colp, ray_row, px0, py);
 
     // framebuffer state of the two pixels, as the reference's cleared textures hold it
     f2 depth_tex = splat(0.0f), win_t = splat(0.0f);
@@ -274,10 +277,10 @@ hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriReco
     const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
     // ev_start / ev_stop (may be null): timestamps of this dispatch itself (hipExtLaunchKernelGGL), i.e. the
     // kernel's own duration as a profiler reports it, without the gap to the preceding kernel
-    if (aux && do_cull) hipExtLaunchKernelGGL((k_primary_p2<true, true>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, shade, ftris, tex, tg);
-    else if (aux) hipExtLaunchKernelGGL((k_primary_p2<true, false>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, shade, ftris, tex, tg);
-    else if (do_cull) hipExtLaunchKernelGGL((k_primary_p2<false, true>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, shade, ftris, tex, tg);
-    else hipExtLaunchKernelGGL((k_primary_p2<false, false>), grid, block, 0, s, ev_start, ev_stop, 0, fp, tris, shade, ftris, tex, tg);
+    if (aux && do_cull) hipExtLaunchKernelGGL((k_primary_p2<true, true>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp, tris, shade, tex, tg);
+    else if (aux) hipExtLaunchKernelGGL((k_primary_p2<true, false>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp, tris, shade, tex, tg);
+    else if (do_cull) hipExtLaunchKernelGGL((k_primary_p2<false, true>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp, tris, shade, tex, tg);
+    else hipExtLaunchKernelGGL((k_primary_p2<false, false>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp, tris, shade, tex, tg);
     return hipGetLastError();
 }
 
