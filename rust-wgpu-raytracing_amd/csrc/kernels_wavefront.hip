@@ -218,7 +218,7 @@ k_primary_bvh(const FrameParams p, const TriRecord *__restrict__ tris, const Sha
     r.mesh = best;
     if (best.have) {  // mesh pass depth test (compute.wgsl:210-215)
         const float current_depth = 1.0f - r.depth_tex;
-        const float depth = to_non_linear_depth(best.t);
+        const float depth = to_non_linear_depth_auto(best.t);
         if (!(depth >= current_depth)) { r.depth_tex = 1.0f - depth; r.obj = (int32_t)best.idx; r.t = best.t; }
     }
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;

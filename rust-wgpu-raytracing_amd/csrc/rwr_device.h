@@ -117,6 +117,14 @@ RWR_DEV float to_non_linear_depth_fast(float depth)
     return __builtin_fmaf(__builtin_fmaf(-kDepthC, q, x), kDepthRC, q);
 }
 
+// to_non_linear_depth for the active lanes: the short form when every one of their distances is in its
+// domain (a wave-uniform choice; the same bits either way).
+RWR_DEV float to_non_linear_depth_auto(float depth)
+{
+    if (__all(depth_fast_domain(depth))) return to_non_linear_depth_fast(depth);
+    return to_non_linear_depth(depth);
+}
+
 // mat4x4 * vec4 with column-major m[col][row]; WGSL: m[0]*v.x + m[1]*v.y + m[2]*v.z + m[3]*v.w
 RWR_DEV void mat4_mul(const float (&m)[4][4], float vx, float vy, float vz, float vw,
                       float &rx, float &ry, float &rz, float &rw)
@@ -145,7 +153,9 @@ RWR_DEV f3 ray_dir_unnormalized(const rwr_camera_inv_uniform &cam, float fx, flo
 RWR_DEV f3 pixel_to_ray_dir(const rwr_camera_inv_uniform &cam, uint32_t x, uint32_t y, float jx, float jy,
                             uint32_t width, uint32_t height)
 {
-    return normalize3(ray_dir_unnormalized(cam, (float)x + jx, (float)y + jy, (float)width, (float)height));
+    const f3 w = ray_dir_unnormalized(cam, (float)x + jx, (float)y + jy, (float)width, (float)height);
+    if (__all(normalize_fast_domain(w))) return normalize3_fast(w);  // same bits, fewer instructions (see normalize3_fast)
+    return normalize3(w);
 }
 
 // FMA dot product and hardware-rsq normalisation for the colour path only.

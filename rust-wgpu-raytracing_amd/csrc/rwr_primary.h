@@ -116,7 +116,7 @@ RWR_DEV void primary_visibility(const FrameParams &p, const TriRecord *__restric
     r.mesh = best;
     if (best.have) {
         const float current_depth = 1.0f - r.depth_tex;  // compute.wgsl:210
-        const float depth = to_non_linear_depth(best.t);
+        const float depth = to_non_linear_depth_auto(best.t);
         if (!(depth >= current_depth)) {
             r.depth_tex = 1.0f - depth;
             r.obj = (int32_t)best.idx;
