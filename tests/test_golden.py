@@ -59,3 +59,67 @@ def test_gpu_reproduces_golden(rwr, gpu_ctx, golden, suzanne, cube):
         assert np.array_equal(got["depth"].view(np.uint32), g["depth"].view(np.uint32)), name
         assert np.abs(got["color_f32"] - g["color_f32"]).max() <= 1e-4, name
         assert np.abs(got["color"].astype(int) - g["color"].astype(int)).max() <= 1, name
+
+
+# ---- frozen outputs of the extended integrator and of the reference's dormant parts (make_golden_ext.py) ----
+GOLDEN_EXT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frames_ext.npz")
+
+
+@pytest.fixture(scope="module")
+def golden_ext():
+    z = np.load(GOLDEN_EXT, allow_pickle=False)
+    names = sorted({k.split("/")[0] for k in z.files})
+    return {n: {k.split("/")[1]: z[k] for k in z.files if k.startswith(n + "/")} for n in names}
+
+
+def _oracle_ext(orc, g, model):
+    cam_inv = g["camera_inv"].view(orc.CAMERA_INV_DTYPE)
+    spheres = g["spheres"].view(orc.SPHERE_DTYPE)
+    if str(g["kind"]) == "path":
+        w, h, spp, bounces, seed, side = map(int, g["size"])
+        inst = g["instances"].view(orc.INSTANCE_DTYPE) if side else None
+        return orc.render_path(cam_inv, orc.make_screen(w, h), orc.make_params(spp, bounces, seed=seed), spheres, model, instances=inst)
+    w, h, ortho = map(int, g["size"])
+    return orc.render_frame_ex(cam_inv, orc.make_screen(w, h), spheres, g["triangles"].view(orc.TRIANGLE_DTYPE), model, ortho=bool(ortho))
+
+
+def test_oracle_reproduces_extended_golden(orc, ref_loader, res_dir, golden_ext):
+    assert set(golden_ext) == {"path_inside_3spp_bounce", "path_outside_4spp", "path_grid2_2spp_bounce",
+                               "dormant_triangles_perspective", "dormant_triangles_ortho"}
+    model = ref_loader.load_model_compute(res_dir, "suzanne_lowpoly.obj")
+    for name, g in golden_ext.items():
+        out = _oracle_ext(orc, g, model)
+        for k in ("obj_id", "hit_t", "depth", "color", "color_f32"):
+            assert np.array_equal(out[k].view(np.uint8), g[k].view(np.uint8)), (name, k)
+    assert (golden_ext["dormant_triangles_ortho"]["obj_id"] <= -10).any()
+    assert (golden_ext["path_grid2_2spp_bounce"]["obj_id"] >= 111).any()     # a face of an instance other than the first
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_extended_golden(rwr, gpu_ctx, golden_ext, suzanne):
+    try:
+        for name, g in golden_ext.items():
+            gpu_ctx.upload_model(suzanne)
+            gpu_ctx.set_spheres(g["spheres"].view(rwr.SPHERE_DTYPE))
+            cam_inv = g["camera_inv"].view(rwr.CAMERA_INV_DTYPE)
+            if str(g["kind"]) == "path":
+                w, h, spp, bounces, seed, side = map(int, g["size"])
+                gpu_ctx.set_triangles(rwr.make_triangles())
+                gpu_ctx.set_instances(g["instances"].view(rwr.INSTANCE_DTYPE) if side else None)
+                params = rwr.make_params(spp=spp, max_bounces=bounces, seed=seed, flags=rwr.FLAG_AUX_OUTPUTS)
+            else:
+                w, h, ortho = map(int, g["size"])
+                gpu_ctx.set_instances(None)
+                gpu_ctx.set_triangles(g["triangles"].view(rwr.TRIANGLE_DTYPE))
+                params = rwr.make_params(flags=rwr.FLAG_AUX_OUTPUTS | (rwr.FLAG_ORTHO_RAYS if ortho else 0))
+            gpu_ctx.resize(w, h)
+            gpu_ctx.render(cam_inv, params)
+            got = gpu_ctx.readback(aux=True)
+            assert np.array_equal(got["obj_id"], g["obj_id"]), name
+            assert np.array_equal(got["hit_t"].view(np.uint32), g["hit_t"].view(np.uint32)), name
+            assert np.array_equal(got["depth"].view(np.uint32), g["depth"].view(np.uint32)), name
+            assert np.all(np.abs(got["color_f32"] - g["color_f32"]) <= 1e-4 + 1e-5 * np.abs(g["color_f32"])), name
+            assert np.abs(got["color"].astype(int) - g["color"].astype(int)).max() <= 1, name
+    finally:
+        gpu_ctx.set_triangles(rwr.make_triangles())
+        gpu_ctx.set_instances(None)
