@@ -191,6 +191,23 @@ hipError_t ensure_slot_targets(rwr_context *ctx, uint32_t i)
     return hipMemsetAsync(sl.d_depth.ptr, 0, n * sizeof(float), sl.stream);
 }
 
+// Per-frame buffers of every active slot for the current scene and screen, so that the first frame
+// does not pay for allocations (the render path re-checks: both calls are no-ops once sized).
+hipError_t ensure_frame_buffers(rwr_context *ctx)
+{
+    const uint32_t total = ctx->n_faces * (ctx->n_instances ? ctx->n_instances : 1u);
+    for (uint32_t i = 0; i < ctx->n_slots; i++) {
+        FrameSlot &sl = ctx->slots[i];
+        hipError_t e;
+        if (total && ((e = sl.d_ftris.ensure(total)) != hipSuccess || (e = sl.d_tnum.ensure(total)) != hipSuccess)) return e;
+        if (ctx->screen.width) {
+            if ((e = sl.d_ray_colp.ensure(2u * (size_t)(((ctx->screen.width + 63u) / 64u) * 32u))) != hipSuccess) return e;
+            if ((e = sl.d_ray_row.ensure(ctx->screen.height + 8u)) != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
 void build_srgb_lut(float *lut)
 {
     // Rgba8UnormSrgb decode (texture.rs:122): the sRGB EOTF, evaluated in double.
@@ -418,6 +435,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     }
     ctx->stream = ctx->own_stream;
     ctx->slots[0].stream = ctx->stream;
+    (void)preload_kernels();   // have the code objects on the device before the first frame asks for them
     if (const char *e2 = std::getenv("RWR_WAVE_CULL_MIN")) ctx->wave_cull_min = (uint32_t)std::strtoul(e2, nullptr, 10);
     if (const char *e4 = std::getenv("RWR_ONE_PIXEL_PER_LANE")) ctx->force_one_pixel = std::atoi(e4) != 0;
     if (const char *e5 = std::getenv("RWR_AUTO_BVH_FACE_PX")) ctx->auto_bvh_face_px = (float)std::atof(e5);
@@ -567,7 +585,10 @@ int rwr_scene_commit(rwr_context *ctx)
     ctx->tex_w = ctx->st_materials[0].tex_w;
     ctx->tex_h = ctx->st_materials[0].tex_h;
     ctx->tris_dirty = true;
-    return rebuild_tris(ctx);
+    const int rc = rebuild_tris(ctx);
+    if (rc != RWR_OK) return rc;
+    RWR_HIP_CHECK(ensure_frame_buffers(ctx));
+    return RWR_OK;
 }
 
 int rwr_scene_upload_mesh(rwr_context *ctx, const rwr_model_vertex_small *verts, uint32_t n_verts,
@@ -632,6 +653,7 @@ int rwr_resize(rwr_context *ctx, const rwr_screen *screen)
         RWR_HIP_CHECK(ensure_slot_targets(ctx, i));
         ctx->slots[i].aux_valid = false;
     }
+    RWR_HIP_CHECK(ensure_frame_buffers(ctx));
     return RWR_OK;
 }
 
@@ -876,6 +898,7 @@ int rwr_ctx_set_frames_in_flight(rwr_context *ctx, uint32_t n)
     if (ctx->cur >= n) ctx->cur = 0;
     for (uint32_t i = 0; i < n; i++)
         if (!ctx->slots[i].d_color.ptr) RWR_HIP_CHECK(ensure_slot_targets(ctx, i));
+    RWR_HIP_CHECK(ensure_frame_buffers(ctx));
     RWR_HIP_CHECK(sync_all(ctx));
     return RWR_OK;
 }

@@ -263,4 +263,18 @@ hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord 
     return hipGetLastError();
 }
 
+hipError_t preload_kernels_primary()
+{
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_frame_setup));
+}
+
+hipError_t preload_kernels()
+{
+    hipError_t e = preload_kernels_primary();
+    if (e == hipSuccess) e = preload_kernels_primary_p2();
+    if (e == hipSuccess) e = preload_kernels_wavefront();
+    return e;
+}
+
 }  // namespace rwr

@@ -284,4 +284,10 @@ hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriReco
     return hipGetLastError();
 }
 
+hipError_t preload_kernels_primary_p2()
+{
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((&k_primary_p2<false, true>)));
+}
+
 }  // namespace rwr

@@ -316,4 +316,10 @@ hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets
     return hipGetLastError();
 }
 
+hipError_t preload_kernels_wavefront()
+{
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((&k_wf_primary<false, true>)));
+}
+
 }  // namespace rwr

@@ -211,6 +211,12 @@ struct SingleTriangles {  // the single-triangle passes of a frame (kept out of 
 hipError_t launch_primary_dormant(hipStream_t s, const FrameParams &fp, const SingleTriangles &st, const TriRecord *tris,
                                   const ShadeRec *shade, const float4 *tex, const Targets &tg);
 
+// kernels_*.hip: resolve one kernel of each translation unit (HIP loads a code object on first use)
+hipError_t preload_kernels();
+hipError_t preload_kernels_primary();
+hipError_t preload_kernels_primary_p2();
+hipError_t preload_kernels_wavefront();
+
 // kernels_selftest.hip: out[0..3] += depth inputs compared, mismatches, normalize inputs compared, mismatches
 hipError_t launch_selftest_exact_math(hipStream_t s, unsigned long long *d_out4, uint32_t normalize_count, uint32_t seed);
 
