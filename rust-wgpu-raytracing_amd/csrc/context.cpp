@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <limits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -274,19 +275,12 @@ void compute_cull_consts(const rwr_camera_inv_uniform &cam, uint32_t width, uint
     cc.enabled = (ok && cc.vxa != 0.0f && cc.vya != 0.0f) ? 1u : 0u;
 }
 
-// Average projected area, in pixels, of a face of the mesh as this camera sees it: the area of the
-// screen rectangle of the mesh's bounding box (clipped to the frame) over half the face count.
-// +inf when any box corner is behind (or beside) the camera — the camera is in or near the mesh and
-// its faces are large on screen — or when the question is meaningless.  The frame kernel walks, per
-// 32x4-pixel tile, every face that may touch the tile, one after the other; when faces are much smaller
-// than a tile (a distant or finely tessellated mesh) the per-ray BVH traversal of k_primary_bvh is
-// faster (tools/dense_probe.py: cube.obj, 428 faces, from 8 units away and beyond — up to 2x) and gives
-// the same frame bit for bit, so the context switches to it for binned scenes (more than 256 faces; a
-// smaller mesh bounds the walk by itself).
-double mean_face_pixels(const CullConsts &cc, const float lo[3], const float hi[3], uint32_t n_tris, uint32_t width,
-                        uint32_t height)
+// Screen rectangle {x0, y0, x1, y1} (pixel coordinates, un-clipped) of the bounding box of the whole mesh as
+// this camera sees it; false when any box corner is behind (or beside) the camera plane — the camera is in or
+// near the mesh — or when culling is off.  Conservative use needs the caller's margin.
+bool mesh_screen_rect(const CullConsts &cc, const float lo[3], const float hi[3], double rect[4])
 {
-    if (!cc.enabled || n_tris == 0) return INFINITY;
+    if (!cc.enabled) return false;
     double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
     for (int c = 0; c < 8; c++) {
         double q[3], vx = 0.0, vy = 0.0, ux = 0.0, uy = 0.0;
@@ -295,13 +289,27 @@ double mean_face_pixels(const CullConsts &cc, const float lo[3], const float hi[
             vx += cc.Vx[k] * q[k]; vy += cc.Vy[k] * q[k]; ux += cc.Ux[k] * q[k]; uy += cc.Uy[k] * q[k];
         }
         // depth along the view direction of this corner (see compute_sphere_rects); must be clearly in front
-        if (!(vx / cc.vxa > 1e-6) || !(vy / cc.vya > 1e-6)) return INFINITY;
+        if (!(vx / cc.vxa > 1e-6) || !(vy / cc.vya > 1e-6)) return false;
         const double x = -ux / vx, y = -uy / vy;
-        if (!std::isfinite(x) || !std::isfinite(y)) return INFINITY;
+        if (!std::isfinite(x) || !std::isfinite(y)) return false;
         x0 = std::fmin(x0, x); x1 = std::fmax(x1, x); y0 = std::fmin(y0, y); y1 = std::fmax(y1, y);
     }
-    x0 = std::fmax(x0, 0.0); y0 = std::fmax(y0, 0.0);
-    x1 = std::fmin(x1, (double)width); y1 = std::fmin(y1, (double)height);
+    rect[0] = x0; rect[1] = y0; rect[2] = x1; rect[3] = y1;
+    return true;
+}
+
+// Average projected area, in pixels, of a face of the mesh: the area of that rectangle (clipped to the
+// frame) over half the face count; +inf when there is no rectangle.  The frame kernel walks, per 32x4-pixel
+// tile, every face that may touch the tile, one after the other; when faces are much smaller than a tile (a
+// distant or finely tessellated mesh) the per-ray BVH traversal of k_primary_bvh is faster
+// (tools/dense_probe.py: cube.obj, 428 faces, from 8 units away and beyond — up to 2x) and gives the same
+// frame bit for bit, so the context switches to it for binned scenes (more than 256 faces; a smaller mesh
+// bounds the walk by itself).
+double mean_face_pixels(bool have_rect, const double rect[4], uint32_t n_tris, uint32_t width, uint32_t height)
+{
+    if (!have_rect || n_tris == 0) return INFINITY;
+    const double x0 = std::fmax(rect[0], 0.0), y0 = std::fmax(rect[1], 0.0);
+    const double x1 = std::fmin(rect[2], (double)width), y1 = std::fmin(rect[3], (double)height);
     if (!(x1 > x0) || !(y1 > y0)) return INFINITY;   // off screen: nothing to trace either way
     return (x1 - x0) * (y1 - y0) / (0.5 * (double)n_tris);
 }
@@ -728,6 +736,21 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     CullConsts cc;
     compute_cull_consts(*camera, ctx->screen.width, ctx->screen.height, cc);
     compute_sphere_rects(cc, ctx->spheres, ctx->n_spheres, ctx->screen.width, ctx->screen.height, fp.sphere_rect);
+    // the whole mesh's screen rectangle: tiles outside it skip the mesh pass altogether (same margins as the spheres')
+    double mesh_rect[4] = {0, 0, 0, 0};
+    const bool have_mesh_rect = ctx->n_tris != 0 && mesh_screen_rect(cc, ctx->aabb_lo, ctx->aabb_hi, mesh_rect);
+    const float inf = std::numeric_limits<float>::infinity();
+    fp.mesh_rect[0] = fp.mesh_rect[1] = -inf; fp.mesh_rect[2] = fp.mesh_rect[3] = inf;
+    if (have_mesh_rect) {
+        fp.mesh_rect[0] = (float)(mesh_rect[0] - 1.0 - 1e-4 * std::fabs(mesh_rect[0]));
+        fp.mesh_rect[1] = (float)(mesh_rect[1] - 1.0 - 1e-4 * std::fabs(mesh_rect[1]));
+        fp.mesh_rect[2] = (float)(mesh_rect[2] + 1.0 + 1e-4 * std::fabs(mesh_rect[2]));
+        fp.mesh_rect[3] = (float)(mesh_rect[3] + 1.0 + 1e-4 * std::fabs(mesh_rect[3]));
+    }
+    for (int k = 0; k < 4; k++) {
+        const double v = k < 2 ? std::floor((double)fp.mesh_rect[k]) : std::ceil((double)fp.mesh_rect[k]);
+        fp.mesh_px[k] = (int32_t)std::fmax(-1e9, std::fmin(1e9, v));   // +-inf -> +-1e9
+    }
     fp.spp = rp.spp;
     fp.seed = rp.seed;
     fp.bounces = rp.max_bounces;
@@ -775,7 +798,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     // faces much smaller than a tile: the per-ray BVH kernel is the faster way to the same frame
     const bool auto_bvh = !wavefront && !dormant && !(rp.flags & (RWR_FLAG_NO_CULL | RWR_FLAG_ONE_PIXEL_PER_LANE)) &&
                           !ctx->force_one_pixel && ctx->n_tris > ctx->bin_min_faces && ctx->auto_bvh_face_px > 0.0f &&
-                          mean_face_pixels(cc, ctx->aabb_lo, ctx->aabb_hi, ctx->n_tris, ctx->screen.width, ctx->screen.height) <
+                          mean_face_pixels(have_mesh_rect, mesh_rect, ctx->n_tris, ctx->screen.width, ctx->screen.height) <
                               (double)ctx->auto_bvh_face_px;
     const bool dispatch_timed = time_this && !wavefront && !dormant && !auto_bvh && !(rp.flags & RWR_FLAG_USE_BVH) &&
                                 !((rp.flags & RWR_FLAG_ONE_PIXEL_PER_LANE) || ctx->force_one_pixel);

@@ -84,10 +84,11 @@ RWR_DEV void shade_mesh_pair(const FrameParams &p, const ShadeRec *__restrict__ 
 #endif
 template <bool AUX, bool CULL>
 __global__ void __launch_bounds__(256, AUX ? 4 : RWR_P2_OCC)
-// (the first seven arguments repeat FrameParams fields: they are what a wave needs first, and the Makefile
-// has their 10 dwords preloaded into SGPRs)
+// (the first eleven arguments repeat FrameParams fields: they are what a wave needs first, and the Makefile
+// has their 14 dwords preloaded into SGPRs)
 k_primary_p2(const FrameTri *__restrict__ ftris, const float4 *__restrict__ ray_colp, const float4 *__restrict__ ray_row,
              uint32_t n_tris, uint32_t row_begin, uint32_t bins_enabled, uint32_t pad0,
+             int32_t mesh_x0, int32_t mesh_y0, int32_t mesh_x1, int32_t mesh_y1,
              const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
              const float4 *__restrict__ tex, const Targets tg)
 {
@@ -115,6 +116,17 @@ k_primary_p2(const FrameTri *__restrict__ ftris, const float4 *__restrict__ ray_
         src = p.bins.lists + (size_t)bin * p.bins.cap;
     }
     n_src = __builtin_amdgcn_readfirstlane(n_src);
+    if (CULL) {  // the tile lies outside the screen rectangle of the whole mesh: scalar integer compares
+        const int32_t wu = __builtin_amdgcn_readfirstlane((int32_t)wave);
+#if RWR_P2_TILE_32x4
+        const int32_t sx0 = (int32_t)blk_x0 + (wu & 1) * 32, sy0 = (int32_t)(row_begin + blockIdx.y * 8u) + (wu >> 1) * 4;
+        const int32_t sx1 = sx0 + 32, sy1 = sy0 + 4;
+#else
+        const int32_t sx0 = (int32_t)blk_x0 + wu * 16, sy0 = (int32_t)(row_begin + blockIdx.y * 8u);
+        const int32_t sx1 = sx0 + 16, sy1 = sy0 + 8;
+#endif
+        if (sx1 < mesh_x0 || sx0 > mesh_x1 || sy1 < mesh_y0 || sy0 > mesh_y1) n_src = 0u;
+    }
     bool valid = lane < n_src;
     uint32_t face = (valid && src) ? src[lane] : lane;
     FrameTri cur;
@@ -277,10 +289,10 @@ hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriReco
     const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
     // ev_start / ev_stop (may be null): timestamps of this dispatch itself (hipExtLaunchKernelGGL), i.e. the
     // kernel's own duration as a profiler reports it, without the gap to the preceding kernel
-    if (aux && do_cull) hipExtLaunchKernelGGL((k_primary_p2<true, true>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp, tris, shade, tex, tg);
-    else if (aux) hipExtLaunchKernelGGL((k_primary_p2<true, false>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp, tris, shade, tex, tg);
-    else if (do_cull) hipExtLaunchKernelGGL((k_primary_p2<false, true>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp, tris, shade, tex, tg);
-    else hipExtLaunchKernelGGL((k_primary_p2<false, false>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp, tris, shade, tex, tg);
+    if (aux && do_cull) hipExtLaunchKernelGGL((k_primary_p2<true, true>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg);
+    else if (aux) hipExtLaunchKernelGGL((k_primary_p2<true, false>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg);
+    else if (do_cull) hipExtLaunchKernelGGL((k_primary_p2<false, true>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg);
+    else hipExtLaunchKernelGGL((k_primary_p2<false, false>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg);
     return hipGetLastError();
 }
 

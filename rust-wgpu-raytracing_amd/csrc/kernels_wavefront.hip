@@ -211,7 +211,11 @@ k_primary_bvh(const FrameParams p, const TriRecord *__restrict__ tris, const Sha
     }
     MeshHit best;
     best.have = false; best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.ndotd = 0.0f; best.idx = 0u;
-    if (p.n_tris) {
+    // wave-uniform: the wave's 8x8 tile lies outside the screen rectangle of the whole mesh (FrameParams::mesh_rect)
+    const float tx = (float)(blockIdx.x * 32u + wave * 8u), ty = (float)(p.row_begin + blockIdx.y * 8u);
+    const bool outside = !(p.flags & RWR_FLAG_NO_CULL) && ((tx + 8.0f < p.mesh_rect[0]) || (tx > p.mesh_rect[2]) ||
+                                                          (ty + 8.0f < p.mesh_rect[1]) || (ty > p.mesh_rect[3]));
+    if (p.n_tris && !outside) {
         if (NODES_IN_LDS) bvh_nearest(s_nodes, bvh.leaf_faces, tris, p.n_tris, s_stack, O, D, best);
         else bvh_nearest(bvh.nodes, bvh.leaf_faces, tris, p.n_tris, s_stack, O, D, best);
     }

@@ -138,6 +138,10 @@ struct FrameParams {
     // conservative pixel-space bounds {x0, y0, x1, y1} of each sphere's silhouette
     // (host-computed per frame, context.cpp); a tile outside them skips the sphere
     float sphere_rect[RWR_MAX_SPHERES][4];
+    // conservative pixel-space bounds of the whole mesh's bounding box (+-inf when the camera is in or near it):
+    // a tile outside skips the mesh pass
+    float mesh_rect[4];
+    int32_t mesh_px[4];   // the same, rounded outwards to whole pixels (scalar compares in the frame kernel)
     float ambient[4];
     float specular[4];
     // Per-frame tables written by k_frame_setup (the frame kernel with centre rays reads them; nothing

@@ -72,6 +72,9 @@ RWR_DEV void primary_visibility(const FrameParams &p, const TriRecord *__restric
             src = p.bins.lists + (size_t)bin * p.bins.cap;
         }
         n_src = __builtin_amdgcn_readfirstlane(n_src);
+        // workgroup-uniform: the 32x8 block lies outside the screen rectangle of the whole mesh
+        if (CULL && ((bx0 + 32.0f < p.mesh_rect[0]) || (bx0 > p.mesh_rect[2]) || (ty0 + 8.0f < p.mesh_rect[1]) || (ty0 > p.mesh_rect[3])))
+            n_src = 0u;
         for (uint32_t base = 0; base < n_src; base += 256u) {
             // level 1: 256 faces vs the block rectangle, order-preserving compaction into LDS
             const uint32_t e0 = base + threadIdx.x;
