@@ -1,0 +1,50 @@
+"""Fuzz: random triangle soups, cameras, sphere sets and frame sizes against the CPU oracle for a given time
+(needs a GPU; the oracle is the checker here exactly as in tests/).  Every frame must match the oracle bit for
+bit in object ids, hit distances and depth, and within 1e-4 in colour.
+
+    python tools/fuzz_parity.py [seed] [seconds]
+"""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import __graft_entry__ as g
+from oracle import oracle as orc, ref_loader
+from test_gpu_random import _soup
+r = g.load_package()
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 30.0)
+rng = np.random.default_rng(seed)
+tex = ref_loader.load_model_compute(r.RES_DIR, "suzanne_lowpoly.obj")["texture"]
+n_frames = n_path = 0
+worst = 0.0
+with r.Context(0) as ctx:
+    while time.time() < t_end:
+        n_faces = int(rng.choice([1, 2, 7, 63, 64, 65, 128, 129, 255, 256, 257, 300, 777, 1500]))
+        model = _soup(ref_loader, rng, n_faces, extent=float(rng.choice([0.5, 2.5, 8.0])), tri_size=float(rng.choice([0.02, 0.05, 0.4, 1.5, 6.0])), tex=tex)
+        w, h = int(rng.integers(1, 260)), int(rng.integers(1, 150))
+        cam = r.make_camera(eye=rng.uniform(-4, 4, 3), target=rng.uniform(-1, 1, 3), aspect=w / h, fovy=float(rng.uniform(15, 110)))
+        ci = r.camera_build_inv_uniform(cam)
+        spheres = r.make_spheres([(tuple(rng.uniform(-3, 3, 3)), float(rng.uniform(0.05, 1.5))) for _ in range(int(rng.integers(0, 9)))])
+        ctx.upload_model(model); ctx.set_spheres(spheres); ctx.resize(w, h)
+        ctx.set_frames_in_flight(int(rng.integers(1, 4)))
+        path = rng.random() < 0.25 and w * h * n_faces < 4e6
+        if path:
+            spp, b, sd = int(rng.choice([1, 2, 3])), int(rng.integers(0, 2)), int(rng.integers(0, 1000))
+            ctx.render(ci, r.make_params(spp=spp, max_bounces=b, seed=sd, flags=r.FLAG_AUX_OUTPUTS))
+            want = orc.render_path(ci.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), orc.make_params(spp, b, seed=sd),
+                                   spheres.view(orc.SPHERE_DTYPE), model)
+            n_path += 1
+        else:
+            ctx.render(ci, r.make_params(flags=r.FLAG_AUX_OUTPUTS))
+            want = orc.render_frame(ci.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), spheres.view(orc.SPHERE_DTYPE), model)
+        got = ctx.readback(aux=True)
+        tag = (seed, n_frames, n_faces, w, h, path)
+        assert np.array_equal(got["obj_id"], want["obj_id"]), tag
+        assert np.array_equal(got["hit_t"].view(np.uint32), want["hit_t"].view(np.uint32)), tag
+        assert np.array_equal(got["depth"].view(np.uint32), want["depth"].view(np.uint32)), tag
+        d = float(np.abs(got["color_f32"] - want["color_f32"]).max())
+        assert d <= 1e-4, tag + (d,)
+        worst = max(worst, d)
+        n_frames += 1
+print(f"ok: {n_frames} frames ({n_path} path-traced), worst colour difference {worst:.2e}")
