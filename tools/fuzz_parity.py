@@ -15,15 +15,23 @@ r = g.load_package()
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 30.0)
 rng = np.random.default_rng(seed)
-tex = ref_loader.load_model_compute(r.RES_DIR, "suzanne_lowpoly.obj")["texture"]
+meshes = [ref_loader.load_model_compute(r.RES_DIR, n) for n in ("suzanne_lowpoly.obj", "cube.obj")]
+tex = meshes[0]["texture"]
 n_frames = n_path = n_dormant = 0
+t_note = time.time()
 worst = 0.0
 with r.Context(0) as ctx:
     while time.time() < t_end:
         n_faces = int(rng.choice([1, 2, 7, 63, 64, 65, 128, 129, 255, 256, 257, 300, 777, 1500]))
-        model = _soup(ref_loader, rng, n_faces, extent=float(rng.choice([0.5, 2.5, 8.0])), tri_size=float(rng.choice([0.02, 0.05, 0.4, 1.5, 6.0])), tex=tex)
+        kind = rng.random()
+        if kind < 0.5:
+            model = _soup(ref_loader, rng, n_faces, extent=float(rng.choice([0.5, 2.5, 8.0])), tri_size=float(rng.choice([0.02, 0.05, 0.4, 1.5, 6.0])), tex=tex)
+        else:   # real meshes: exactly shared edges and vertices (inclusive edge tests, lowest-index ties)
+            model = meshes[int(rng.integers(0, len(meshes)))]
+            n_faces = len(model["faces"])
         w, h = int(rng.integers(1, 260)), int(rng.integers(1, 150))
-        cam = r.make_camera(eye=rng.uniform(-4, 4, 3), target=rng.uniform(-1, 1, 3), aspect=w / h, fovy=float(rng.uniform(15, 110)))
+        cam = r.make_camera(eye=rng.uniform(-4, 4, 3) * float(rng.choice([0.1, 1.0, 1.0, 6.0])), target=rng.uniform(-1, 1, 3), aspect=w / h,
+                            fovy=float(rng.choice([rng.uniform(15, 110), rng.uniform(1, 15), rng.uniform(110, 175)])))
         ci = r.camera_build_inv_uniform(cam)
         spheres = r.make_spheres([(tuple(rng.uniform(-3, 3, 3)), float(rng.uniform(0.05, 1.5))) for _ in range(int(rng.integers(0, 9)))])
         ctx.upload_model(model); ctx.set_spheres(spheres); ctx.resize(w, h)
@@ -77,4 +85,7 @@ with r.Context(0) as ctx:
         assert d <= 1e-4, tag + (d,)
         worst = max(worst, d)
         n_frames += 1
+        if time.time() - t_note > 30.0:
+            t_note = time.time()
+            print(f"... {n_frames} frames so far", flush=True)
 print(f"ok: {n_frames} frames ({n_path} path-traced, {n_dormant} with single triangles / orthographic rays), worst colour difference {worst:.2e}")
