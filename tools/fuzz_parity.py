@@ -34,9 +34,20 @@ with r.Context(0) as ctx:
                             fovy=float(rng.choice([rng.uniform(15, 110), rng.uniform(1, 15), rng.uniform(110, 175)])))
         ci = r.camera_build_inv_uniform(cam)
         spheres = r.make_spheres([(tuple(rng.uniform(-3, 3, 3)), float(rng.uniform(0.05, 1.5))) for _ in range(int(rng.integers(0, 9)))])
-        ctx.upload_model(model); ctx.set_spheres(spheres); ctx.resize(w, h)
+        parts = None
+        if kind < 0.5 and rng.random() < 0.3 and n_faces < 400:   # a second part with its own material and texture
+            tex2 = rng.integers(0, 256, (int(rng.integers(1, 40)), int(rng.integers(1, 40)), 4), dtype=np.uint8)
+            other = _soup(ref_loader, rng, int(rng.integers(1, 200)), extent=2.0, tri_size=0.5, tex=tex2)
+            other["material"]["ambient"], other["material"]["specular"] = rng.uniform(0, 0.3, 3), rng.uniform(0, 1, 3)
+            parts = [model, other]
+            ctx.upload_parts(parts)
+        else:
+            ctx.upload_model(model)
+        ctx.set_spheres(spheres); ctx.resize(w, h)
         ctx.set_frames_in_flight(int(rng.integers(1, 4)))
-        path = rng.random() < 0.25 and w * h * n_faces < 4e6
+        path = (rng.random() < 0.25 or parts is not None) and w * h * n_faces < 4e6   # several parts: the oracle's path renderer
+        if parts is not None and not path:
+            ctx.upload_model(model); parts = None
         dormant = (not path) and rng.random() < 0.12 and w * h * n_faces < 2e7
         inst = None
         if path and rng.random() < 0.4 and n_faces < 400:   # rigid instances: rotation about y + translation
@@ -59,10 +70,11 @@ with r.Context(0) as ctx:
                                        tris.view(orc.TRIANGLE_DTYPE), model, ortho=ortho)
             n_dormant += 1
         elif path:
-            spp, b, sd = int(rng.choice([1, 2, 3])), int(rng.integers(0, 2)), int(rng.integers(0, 1000))
+            spp, b, sd = int(rng.choice([1, 1, 2, 3])), int(rng.integers(0, 2)), int(rng.integers(0, 1000))
             ctx.render(ci, r.make_params(spp=spp, max_bounces=b, seed=sd, flags=r.FLAG_AUX_OUTPUTS))
             want = orc.render_path(ci.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), orc.make_params(spp, b, seed=sd),
-                                   spheres.view(orc.SPHERE_DTYPE), model, instances=None if inst is None else inst.view(orc.INSTANCE_DTYPE))
+                                   spheres.view(orc.SPHERE_DTYPE), parts if parts is not None else model,
+                                   instances=None if inst is None else inst.view(orc.INSTANCE_DTYPE))
             n_path += 1
         else:
             ctx.render(ci, r.make_params(flags=r.FLAG_AUX_OUTPUTS))
