@@ -237,10 +237,18 @@ def main() -> int:
         serial_kernel_us, _ = ctx.kernel_timing_stats()
         ctx.set_kernel_timing(0)
 
+    render_only_ms = None
     if use_dist:
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        # outside the timed region: the same band WITHOUT the gather, so that the line shows how the frame's time
+        # splits between rendering (which scales with the rank count) and the single collective (which does not)
+        n_ro = max(20, min(300, args.steps // 4))
+        ctx.timer_begin()
+        for _ in range(n_ro):
+            render()
+        render_only_ms = ctx.timer_end() / n_ro
+        t = torch.tensor([elapsed, dev_ms, render_only_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
+        elapsed, dev_ms, render_only_ms = float(t[0]), float(t[1]), float(t[2])
 
     # path segments actually traced: W*H*spp primary rays + the bounce rays the queue carried
     primary_rays, bounce_rays = ctx.last_render_stats()
@@ -303,6 +311,8 @@ def main() -> int:
         }
         if serial_ms_per_frame is not None:
             out["ms_per_frame_one_in_flight"] = round(serial_ms_per_frame, 5)   # frame latency: each frame waits for the previous
+        if render_only_ms is not None:
+            out["ms_per_frame_render_only"] = round(render_only_ms, 5)   # slowest rank's band, no gather (not timed above)
         if gathered_ok is not None:
             out["config"]["gathered_frame_ok"] = gathered_ok
     ctx.close()
