@@ -13,9 +13,12 @@ process per GPU) and every step ends with ONE RCCL gather of the finished bands
 to rank 0 (north_star) — total work is fixed, so "scaling" is "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     — dominant kernel vs the HBM roof (algorithmic bytes = 8 B/pixel:
-                 RGBA8 + R32F store), duration from HIP events on the
-                 launch stream;
+  roofline     — dominant kernel against BOTH roofs: the binding one (VALU issue: the
+                 kernel's SQ_ACTIVE_INST_VALU from the committed PMC pass x 4 cycles /
+                 SIMDs / the shader clock measured live in this run) and HBM (algorithmic
+                 bytes = 8 B/pixel: RGBA8 + R32F store); the duration is the
+                 average time per launch of the timed region, from HIP events on the
+                 launch stream(s).  No per-launch event sits inside the timed region;
   cpu_baseline — the CPU oracle (a port of the reference shaders; the reference's
                  own wgpu/llvmpipe path cannot be built here) timed on the host
                  cores on a bounded sample of the same workload.
@@ -96,7 +99,7 @@ def cpu_baseline(cfg, budget_s: float) -> dict:
         "value": round(w * h / med / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port", "host_threads_visible": os.cpu_count(),
         "ms_per_frame": round(med * 1e3, 2),
         "sample": f"{len(times)} full {w}x{h} frames of the same workload (median), brute-force per-pixel loop as in the WGSL, "
-                  f"gcc -O2 + OpenMP rows; reference wgpu/llvmpipe path not buildable here (no Rust toolchain, no Vulkan ICD)",
+                  f"gcc -O3 -march=x86-64-v3 -ffp-contract=off + OpenMP rows; reference wgpu/llvmpipe path not buildable here (no Rust toolchain, no Vulkan ICD)",
     }
 
 
@@ -200,15 +203,18 @@ def main() -> int:
         if use_dist:
             dist.barrier()
 
+    # Shader clock and VALU issue cost under load, for the VALU roof (about 15 ms of arithmetic on every CU).  It runs
+    # here, before the warm-up steps, like the scene upload and the BVH build: setup, not a step.
+    clk = ctx.measure_valu_clock(8) if rank == 0 else None
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     barrier()
 
-    # dominant-kernel duration: HIP events around that kernel alone, on its launch stream, for a
-    # sample of the frames INSIDE the timed region (every 16th frame at most 256 brackets)
-    ctx.set_kernel_timing(int(os.environ.get("RWR_BENCH_TIMING_EVERY", max(1, args.steps // 128))))
-    # timed region: exactly K steps; HIP events on the launch stream for the whole region
+    # timed region: exactly K steps.  Nothing but the frames themselves is enqueued inside it: the two
+    # HIP events of timer_begin / timer_end sit on the launch stream before the first and after the last frame.
+    ctx.set_kernel_timing(0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ctx.timer_begin()            # HIP events on the launch stream(s); timer_end joins every frame in flight
@@ -218,11 +224,18 @@ def main() -> int:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+
+    # ---- everything below is OUTSIDE the timed region --------------------------------------------
+    # (a) duration of the dominant kernel's own dispatches (start/stop timestamps of the dispatch, as a
+    #     profiler reports them) while frames are pipelined exactly as in the timed region
+    n_probe = max(64, min(512, args.steps)) if primary_only else max(2, min(8, args.steps))
+    ctx.set_kernel_timing(4 if primary_only else 1)
+    for _ in range(n_probe):
+        step()
     kernel_us, kernel_samples = ctx.kernel_timing_stats()
     ctx.set_kernel_timing(0)
-
-    # outside the timed region: the same frames one at a time (no overlap between frames) — the latency of
-    # a frame and the duration of a lone kernel launch, reported next to the pipelined numbers
+    # (b) the same frames one at a time (no overlap between frames): the latency of a frame and the
+    #     duration of a lone kernel launch
     serial_ms_per_frame, serial_kernel_us = None, None
     if fif > 1:
         ctx.set_frames_in_flight(1)
@@ -236,7 +249,6 @@ def main() -> int:
         serial_ms_per_frame = ctx.timer_end() / n_serial
         serial_kernel_us, _ = ctx.kernel_timing_stats()
         ctx.set_kernel_timing(0)
-
     render_only_ms = None
     if use_dist:
         # outside the timed region: the same band WITHOUT the gather, so that the line shows how the frame's time
@@ -264,40 +276,68 @@ def main() -> int:
         # the gathered frame must equal what a single GPU renders (checked once, outside the timed region)
         torch.cuda.synchronize()
         got = frame.cpu().numpy().reshape(h, w, 4)
-        gathered_ok = bool(got.any()) and (world > 1 or bool((got == ctx.readback()["color"]).all()))
+        ctx.render(cam_inv, params)                      # the whole frame on this rank alone
+        gathered_ok = bool((got == ctx.readback()["color"]).all())
     out = None
     if rank == 0:
-        launch_s = kernel_us * 1e-6 if kernel_samples else dev_ms * 1e-3 / args.steps
-        if cfg["spp"] == 1 and cfg["bounces"] == 0:
-            # dominant kernel: k_primary — one launch per step on this rank's band (plus the
-            # one-workgroup k_frame_setup that precedes it on the same stream)
+        # Average duration of one launch of the dominant kernel(s) over the timed region: HIP events on the launch
+        # stream(s) around exactly K steps / K.  With two frames in flight the dispatches overlap, so a single
+        # dispatch's own start-to-stop time (launch_us_pipelined, what a kernel trace lists) is LONGER than this;
+        # it cannot serve as a per-step cost and is reported for reference only.
+        launch_s = dev_ms * 1e-3 / args.steps
+        primary_only_cfg = cfg["spp"] == 1 and cfg["bounces"] == 0
+        if primary_only_cfg:
+            # dominant kernel: the fused frame kernel — one launch per step on this rank's band (plus the
+            # 13-workgroup k_frame_setup that precedes it on the same stream)
             algo_bytes = ALGO_BYTES_PER_PIXEL * w * (r1 - r0)
-            kernel = "k_primary"
-            note = ("8 B/pixel (RGBA8 + R32F store, each pixel once); the scene (face records + 4 MiB linear-float texture) is "
-                    "cache resident, so the kernel is bound by its arithmetic and its latency chain, not by HBM: DESIGN.md §4.1. "
-                    "launch_us is the duration of a launch INSIDE the timed region, where two frames are in flight and "
-                    "their kernels share the GPU; launch_us_serial is a lone launch")
+            kernel = "k_primary_p2"
+            note = ("VALU-bound: the scene (face records + 4 MiB linear-float texture) is cache resident and HBM sees only the "
+                    "8 B/pixel store (RGBA8 + R32F, each pixel once), so hbm.frac is small by construction (SURVEY §8(d)); "
+                    "frac = VALU issue time of one launch (SQ_ACTIVE_INST_VALU x 4 cycles / SIMDs / measured shader clock) / "
+                    "duration_us; duration_us = HIP-event time of the timed region / K launches")
         else:
             # wavefront: SURVEY §8(d) contract figure, 96 B per path segment + 20 B per pixel per frame
             algo_bytes = int(96 * rays_per_frame / world + 20 * w * (r1 - r0))
-            kernel = "k_wf_primary + k_wf_bounce (all sample passes of one frame)"
-            note = "96 B per path segment (ray + hit record, written and read) + 20 B per pixel (RGBA32F + RGBA8)"
-        achieved = algo_bytes / launch_s / 1e9
-        # HBM bytes per launch from the committed PMC passes (not collectable live inside this process);
-        # only valid for the exact launch they were measured on
-        traffic = None
-        if kernel == "k_primary" and world == 1 and args.config == "cfg2":
+            kernel = "k_wf_primary + k_wf_bounce + k_wf_resolve (all launches of one frame)"
+            note = ("VALU-bound (BVH traversal of incoherent rays).  hbm.achieved uses SURVEY §8(d)'s contract figure, 96 B per path "
+                    "segment (ray + hit record, written and read) + 20 B per pixel, which this design deliberately does not move "
+                    "(primary rays and hit records stay in registers): traffic is what the counters saw")
+        # Counters of the dominant kernel(s) per step from the committed PMC passes (they cannot be collected live
+        # inside this process); valid only for the exact workload they were measured on.
+        counters = None
+        if world == 1:
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-                    traffic = json.load(fh)["k_primary"]["traffic_bytes_per_launch"]
-            except (OSError, KeyError, ValueError):
-                traffic = None
-        roofline = {
-            "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(launch_s * 1e6, 3),
-            "launch_us_samples": kernel_samples, "step_us_on_stream": round(dev_ms * 1e3 / args.steps, 3), "note": note,
-        }
+                import glob
+                with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")))[-1]) as fh:
+                    counters = json.load(fh).get(args.config)
+            except (OSError, IndexError, ValueError):
+                counters = None
+        traffic = counters.get("traffic_bytes_per_step") if counters else None
+        n_simd = 4 * info["cu_count"]
+        valu = None
+        if counters and counters.get("SQ_ACTIVE_INST_VALU") and clk:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs (MI355X_MICROARCH.md constants table)
+            valu_us = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / n_simd / clk["shader_mhz"]
+            valu = {"issue_us_per_step": round(valu_us, 3), "SQ_ACTIVE_INST_VALU": counters["SQ_ACTIVE_INST_VALU"],
+                    "SQ_INSTS_VALU": counters.get("SQ_INSTS_VALU"), "simds": n_simd,
+                    "shader_mhz_measured": round(clk["shader_mhz"], 1),
+                    "cycles_per_wave64_v_fma_f32": round(clk["cycles_per_v_fma_f32"], 3),
+                    "cycles_per_wave64_v_pk_fma_f32": round(clk["cycles_per_v_pk_fma_f32"], 3),
+                    "frac": round(valu_us * 1e-6 / launch_s, 4), "counters_from": counters.get("source")}
+        hbm_achieved = algo_bytes / launch_s / 1e9
+        hbm = {"achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 5),
+               "algorithmic_bytes_per_step": algo_bytes}
+        if valu:
+            roofline = {"bound": "valu", "kernel": kernel, "achieved": valu["issue_us_per_step"], "peak": round(launch_s * 1e6, 3),
+                        "unit": "us of VALU issue per step / us per step", "frac": valu["frac"], "traffic": traffic}
+        else:   # no counter record for this workload: only the HBM figure can be stated
+            roofline = {"bound": "hbm", "kernel": kernel, "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": hbm["frac"], "traffic": traffic}
+        roofline.update({
+            "valu": valu, "hbm": hbm, "valu_frac": valu["frac"] if valu else None, "hbm_frac": hbm["frac"],
+            "duration_us": round(launch_s * 1e6, 3), "launch_us_pipelined": round(kernel_us, 3) if kernel_samples else None,
+            "launch_us_pipelined_samples": kernel_samples, "timed_region_instrumented": False, "note": note,
+        })
         if serial_kernel_us:
             roofline["launch_us_serial"] = round(serial_kernel_us, 3)
         out = {

@@ -273,6 +273,12 @@ RWR_API int rwr_last_render_stats(rwr_context *ctx, uint64_t *primary_rays, uint
  * mismatches}.  A non-zero mismatch count is a bug. */
 RWR_API int rwr_selftest_exact_math(rwr_context *ctx, uint32_t normalize_count, uint32_t seed, uint64_t out4[4]);
 
+/* Measurement aid for roofline accounting (bench.py): runs a short f32 VALU loop with `waves_per_simd` (1..8)
+ * waves on every SIMD and stamps the shader cycle counter against the constant 100 MHz counter.
+ * out4 = {shader clock in MHz under v_fma_f32 load, shader cycles a SIMD spends per wave64 v_fma_f32,
+ *         shader cycles per wave64 v_pk_fma_f32, shader clock in MHz under v_pk_fma_f32 load}. */
+RWR_API int rwr_measure_valu_clock(rwr_context *ctx, uint32_t waves_per_simd, double out4[4]);
+
 /* ---------------------------------------------- host-side L2 surface (CPU) -- */
 
 /* CameraInvUniform::update_view_proj, src/lib.rs:105-111 with camera.rs:20-30. */

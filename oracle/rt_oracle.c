@@ -272,11 +272,15 @@ static inline v3 tex_sample_bilinear(const Tex *t, float u, float v)
     return V3(c[0], c[1], c[2]);
 }
 
-/* rgba8unorm store: clamp to [0,1], scale, round half up. */
+/* rgba8unorm store (compute.wgsl:237, textureStore to an rgba8unorm texture): the float -> UNORM
+ * conversion of the WebGPU / Vulkan specs, clamp to [0,1] then round(c * 255).  Both specs leave the
+ * handling of exact ties to the implementation (Vulkan: "round to nearest even is preferred"); this
+ * oracle fixes ROUND TO NEAREST, TIES TO EVEN (rintf in the default rounding mode), which is also
+ * what the store conversion of the target hardware does.  NaN stores 0. */
 static inline uint8_t unorm8(float c)
 {
     float cc = fminf(fmaxf(c, 0.0f), 1.0f);
-    return (uint8_t)floorf(cc * 255.0f + 0.5f);
+    return (uint8_t)rintf(cc * 255.0f);
 }
 
 /* ----------------------------------------------------------- the scene -- */

@@ -3,6 +3,7 @@
 // one HIP stream and a handful of device buffers.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <limits>
 #include <cstdarg>
@@ -990,6 +991,42 @@ int rwr_selftest_exact_math(rwr_context *ctx, uint32_t normalize_count, uint32_t
     RWR_HIP_CHECK(hipMemcpyAsync(h, d_out.ptr, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 4; k++) out4[k] = h[k];
+    return RWR_OK;
+}
+
+int rwr_measure_valu_clock(rwr_context *ctx, uint32_t waves_per_simd, double out4[4])
+{
+    if (!ctx || !out4) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (waves_per_simd < 1u || waves_per_simd > 8u) return set_error(RWR_ERR_INVALID_ARGUMENT, "waves_per_simd must be 1..8");
+    DeviceGuard g(ctx->device);
+    hipDeviceProp_t prop;
+    RWR_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+    const uint32_t n_wg = (uint32_t)prop.multiProcessorCount * waves_per_simd, n_waves = n_wg * 4u, iters = 1u << 15;
+    struct Scoped {
+        DeviceBuffer<ulonglong2> b;
+        ~Scoped() { b.release(); }
+    } scoped;
+    RWR_HIP_CHECK(scoped.b.ensure(n_waves));
+    std::vector<ulonglong2> h(n_waves);
+    RWR_HIP_CHECK(sync_all(ctx));
+    for (int mode = 0; mode < 2; mode++) {
+        // an untimed launch first: the stamped one then starts on a busy, clocked-up chip
+        RWR_HIP_CHECK(launch_measure_valu(ctx->stream, mode, scoped.b.ptr, n_wg, iters));
+        RWR_HIP_CHECK(launch_measure_valu(ctx->stream, mode, scoped.b.ptr, n_wg, iters));
+        RWR_HIP_CHECK(hipMemcpyAsync(h.data(), scoped.b.ptr, n_waves * sizeof(ulonglong2), hipMemcpyDeviceToHost, ctx->stream));
+        RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        std::vector<double> cyc(n_waves), mhz(n_waves);
+        for (uint32_t i = 0; i < n_waves; i++) {
+            cyc[i] = (double)h[i].x;
+            mhz[i] = h[i].y ? (double)h[i].x / (double)h[i].y * 100.0 : 0.0;
+        }
+        std::nth_element(cyc.begin(), cyc.begin() + n_waves / 2, cyc.end());
+        std::nth_element(mhz.begin(), mhz.begin() + n_waves / 2, mhz.end());
+        // every SIMD issued waves_per_simd * iters * 8 wave instructions while a wave's stamps were apart
+        const double per_instr = cyc[n_waves / 2] / ((double)waves_per_simd * iters * 8.0);
+        if (mode == 0) { out4[0] = mhz[n_waves / 2]; out4[1] = per_instr; }
+        else { out4[2] = per_instr; out4[3] = mhz[n_waves / 2]; }
+    }
     return RWR_OK;
 }
 

@@ -71,6 +71,48 @@ k_selftest_normalize(unsigned long long *out, uint32_t count, uint32_t seed)  //
     atomicAdd(&out[3], bad);
 }
 
+// Shader clock and f32 VALU issue rate under load, for the roofline accounting of bench.py: every wave runs
+// `iters` rounds of eight independent v_fma_f32 (MODE 0) or v_pk_fma_f32 (MODE 1) chains and stamps the shader
+// cycle counter (s_memtime, one tick per shader cycle) and the constant 100 MHz counter (s_memrealtime) around
+// them (MI355X_MICROARCH.md: in-kernel clock = d s_memtime / d s_memrealtime * 100 MHz).  out[wave] =
+// {cycles, realtime ticks}.  The launch puts `waves_per_simd` waves on every SIMD at once.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_measure_valu(ulonglong2 *out, uint32_t iters, float s)
+{
+    float a0 = (float)threadIdx.x, a1 = a0 + 1.0f, a2 = a0 + 2.0f, a3 = a0 + 3.0f, a4 = a0 + 4.0f, a5 = a0 + 5.0f, a6 = a0 + 6.0f, a7 = a0 + 7.0f;
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6};
+    const f2 sv = {s, s};
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    for (uint32_t i = 0; i < iters; i++) {
+        if (MODE == 0) {
+            a0 = __builtin_fmaf(a0, s, a0); a1 = __builtin_fmaf(a1, s, a1); a2 = __builtin_fmaf(a2, s, a2); a3 = __builtin_fmaf(a3, s, a3);
+            a4 = __builtin_fmaf(a4, s, a4); a5 = __builtin_fmaf(a5, s, a5); a6 = __builtin_fmaf(a6, s, a6); a7 = __builtin_fmaf(a7, s, a7);
+        } else {
+            p0 = fma2(p0, sv, p0); p1 = fma2(p1, sv, p1); p2 = fma2(p2, sv, p2); p3 = fma2(p3, sv, p3);
+            p4 = fma2(p4, sv, p4); p5 = fma2(p5, sv, p5); p6 = fma2(p6, sv, p6); p7 = fma2(p7, sv, p7);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    const float sink = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + p4.x + p4.y +
+                       p5.x + p5.y + p6.x + p6.y + p7.x + p7.y;
+    if ((threadIdx.x & 63u) == 0u || sink == 12345.678f)  // the sink keeps the chains alive
+        out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = make_ulonglong2(c1 - c0, r1 - r0);
+}
+
+hipError_t launch_measure_valu(hipStream_t s, int mode, ulonglong2 *d_out, uint32_t n_workgroups, uint32_t iters)
+{
+    if (mode == 0) hipLaunchKernelGGL((k_measure_valu<0>), dim3(n_workgroups), dim3(256), 0, s, d_out, iters, 1.0001f);
+    else hipLaunchKernelGGL((k_measure_valu<1>), dim3(n_workgroups), dim3(256), 0, s, d_out, iters, 1.0001f);
+    return hipGetLastError();
+}
+
 hipError_t launch_selftest_exact_math(hipStream_t s, unsigned long long *d_out4, uint32_t normalize_count, uint32_t seed)
 {
     hipLaunchKernelGGL(k_selftest_depth, dim3(8192), dim3(256), 0, s, d_out4);

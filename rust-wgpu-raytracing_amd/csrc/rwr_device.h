@@ -305,8 +305,8 @@ RWR_DEV Shaded shade_mesh(const ShadeRec &S, float eu, float ev, float ndotd, f3
 }
 
 // rgba8unorm store conversion, one v_cvt_pk_u8_f32 per channel: it saturates to [0, 255] (NaN -> 0)
-// and rounds to nearest (ties to even where the texture-store rule rounds half up: an exact tie moves
-// the byte by one LSB, like any 1e-7 difference next to a rounding boundary does).
+// and rounds to nearest, ties to even — the rule the oracle states for the store (oracle/rt_oracle.c
+// unorm8; the WebGPU / Vulkan float -> UNORM conversion leaves exact ties to the implementation).
 RWR_DEV uint32_t pack_rgba8_scaled(float r255, float g255, float b255, uint32_t alpha_bits)
 {
     uint32_t v = alpha_bits;

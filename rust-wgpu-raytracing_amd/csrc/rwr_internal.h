@@ -224,6 +224,9 @@ hipError_t preload_kernels_wavefront();
 // kernels_selftest.hip: out[0..3] += depth inputs compared, mismatches, normalize inputs compared, mismatches
 hipError_t launch_selftest_exact_math(hipStream_t s, unsigned long long *d_out4, uint32_t normalize_count, uint32_t seed);
 
+// kernels_selftest.hip: d_out[wave] = {shader cycles, 100 MHz ticks} around iters * 8 v_fma_f32 (mode 0) / v_pk_fma_f32 (mode 1)
+hipError_t launch_measure_valu(hipStream_t s, int mode, ulonglong2 *d_out, uint32_t n_workgroups, uint32_t iters);
+
 hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const rwr_camera_inv_uniform &cam, uint32_t width,
                               uint32_t height, const CullRec *cull, const TriRecord *tris, uint32_t n_tris,
                               const FrameSetupOut &out);

@@ -147,6 +147,14 @@ def test_srgb_table_and_bilinear_sampler(orc):
 def test_unorm8_store(orc):
     L = orc.lib()
     assert [L.or_unorm8(v) for v in (-1.0, 0.0, 0.5, 1.0, 2.0, float("nan"))] == [0, 0, 128, 255, 255, 0]
+    # exact ties round to the EVEN byte (the oracle's stated store rule = v_cvt_pk_u8_f32 on the GPU)
+    ties = 0
+    for k in range(255):
+        c = np.float32(k + 0.5) / np.float32(255.0)
+        if np.float32(c * np.float32(255.0)) == np.float32(k + 0.5):
+            ties += 1
+            assert L.or_unorm8(float(c)) == (k if k % 2 == 0 else k + 1), k
+    assert ties > 20
 
 
 def test_controller_s_times_15(orc):
