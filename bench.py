@@ -230,10 +230,14 @@ def main() -> int:
     #     profiler reports them) while frames are pipelined exactly as in the timed region
     n_probe = max(64, min(512, args.steps)) if primary_only else max(2, min(8, args.steps))
     ctx.set_kernel_timing(4 if primary_only else 1)
+    probe_us = int(max(200.0, min(50000.0, 0.6 * n_probe * dev_ms * 1e3 / args.steps)))
+    if rank == 0:
+        ctx.clock_probe_start(probe_us)   # one idle wave on a side stream: the shader clock WHILE these frames render
     for _ in range(n_probe):
         step()
     kernel_us, kernel_samples = ctx.kernel_timing_stats()
     ctx.set_kernel_timing(0)
+    workload_mhz = ctx.clock_probe_read() if rank == 0 else None
     # (b) the same frames one at a time (no overlap between frames): the latency of a frame and the
     #     duration of a lone kernel launch
     serial_ms_per_frame, serial_kernel_us = None, None
@@ -317,10 +321,10 @@ def main() -> int:
         valu = None
         if counters and counters.get("SQ_ACTIVE_INST_VALU") and clk:
             # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs (MI355X_MICROARCH.md constants table)
-            valu_us = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / n_simd / clk["shader_mhz"]
+            valu_us = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / n_simd / workload_mhz
             valu = {"issue_us_per_step": round(valu_us, 3), "SQ_ACTIVE_INST_VALU": counters["SQ_ACTIVE_INST_VALU"],
                     "SQ_INSTS_VALU": counters.get("SQ_INSTS_VALU"), "simds": n_simd,
-                    "shader_mhz_measured": round(clk["shader_mhz"], 1),
+                    "shader_mhz_while_rendering": round(workload_mhz, 1), "shader_mhz_under_fma_load": round(clk["shader_mhz"], 1),
                     "cycles_per_wave64_v_fma_f32": round(clk["cycles_per_v_fma_f32"], 3),
                     "cycles_per_wave64_v_pk_fma_f32": round(clk["cycles_per_v_pk_fma_f32"], 3),
                     "frac": round(valu_us * 1e-6 / launch_s, 4), "counters_from": counters.get("source")}

@@ -278,6 +278,11 @@ RWR_API int rwr_selftest_exact_math(rwr_context *ctx, uint32_t normalize_count, 
  * out4 = {shader clock in MHz under v_fma_f32 load, shader cycles a SIMD spends per wave64 v_fma_f32,
  *         shader cycles per wave64 v_pk_fma_f32, shader clock in MHz under v_pk_fma_f32 load}. */
 RWR_API int rwr_measure_valu_clock(rwr_context *ctx, uint32_t waves_per_simd, double out4[4]);
+/* The shader clock under the caller's OWN workload: _start launches one idle-spinning wave on a private stream for
+ * `micros` microseconds (asynchronous; render while it runs), _read waits for it and returns
+ * d(shader cycle counter) / d(100 MHz counter) x 100 MHz. */
+RWR_API int rwr_clock_probe_start(rwr_context *ctx, uint32_t micros);
+RWR_API int rwr_clock_probe_read(rwr_context *ctx, double *shader_mhz);
 
 /* ---------------------------------------------- host-side L2 surface (CPU) -- */
 

@@ -110,7 +110,7 @@ def lib() -> C.CDLL:
         "rwr_write_png_rgba8": [C.c_char_p, vp, u32, u32, i32, i32],
         "rwr_ctx_set_kernel_timing": [vp, u32], "rwr_kernel_timing_stats": [vp, vp, vp],
         "rwr_selftest_exact_math": [vp, u32, u32, vp], "rwr_ctx_set_frames_in_flight": [vp, u32],
-        "rwr_measure_valu_clock": [vp, u32, vp],
+        "rwr_measure_valu_clock": [vp, u32, vp], "rwr_clock_probe_start": [vp, u32], "rwr_clock_probe_read": [vp, vp],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
@@ -400,6 +400,14 @@ class Context:
         out = (C.c_double * 4)()
         _check(lib().rwr_measure_valu_clock(self._h, waves_per_simd, out))
         return {"shader_mhz": out[0], "cycles_per_v_fma_f32": out[1], "cycles_per_v_pk_fma_f32": out[2], "shader_mhz_pk": out[3]}
+
+    def clock_probe_start(self, micros: int):
+        _check(lib().rwr_clock_probe_start(self._h, micros))
+
+    def clock_probe_read(self) -> float:
+        mhz = C.c_double()
+        _check(lib().rwr_clock_probe_read(self._h, C.byref(mhz)))
+        return mhz.value
 
     def last_render_stats(self) -> tuple[int, int]:
         a, b = C.c_uint64(), C.c_uint64()

@@ -117,9 +117,13 @@ struct rwr_context {
     float auto_bvh_face_px = 150.0f;   // tunable: RWR_AUTO_BVH_FACE_PX (0 = never pick the BVH kernel by itself)
     // wavefront integrator state
     DeviceBuffer<float4> d_accum, d_q0, d_q1;
-    DeviceBuffer<float2> d_q2;
-    DeviceBuffer<uint32_t> d_seg_count, d_seg_total;
-    uint32_t last_segments = 0;
+    DeviceBuffer<float> d_q2;
+    DeviceBuffer<unsigned long long> d_wf_masks;
+    DeviceBuffer<uint16_t> d_wf_sorted;
+    DeviceBuffer<uint32_t> d_wave_total;
+    uint32_t wf_group = 16;         // samples per launch group; tunable: RWR_WF_GROUP (1..32)
+    float wf_packet_fill = 0.25f;   // pools filled at least this much are traced as packets; tunable: RWR_WF_PACKET_FILL (> 1: never)
+    uint32_t last_segments = 0;     // tiles of the last wavefront frame
     uint32_t last_spp = 0;
     bool last_had_bounce = false;
     // one decoded texture per scene part (texels decoded to linear f32 at upload, Rgba8UnormSrgb semantics)
@@ -151,6 +155,9 @@ struct rwr_context {
     std::vector<hipEvent_t> timing_events;  // pairs
     uint32_t timing_pairs = 0;
     uint32_t wave_cull_min = 4;  // tunable: RWR_WAVE_CULL_MIN
+    // shader-clock probe (rwr_clock_probe_start / _read): one spinning wave on its own stream
+    hipStream_t probe_stream = nullptr;
+    DeviceBuffer<ulonglong2> d_probe;
 };
 
 namespace {
@@ -448,6 +455,8 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     if (const char *e2 = std::getenv("RWR_WAVE_CULL_MIN")) ctx->wave_cull_min = (uint32_t)std::strtoul(e2, nullptr, 10);
     if (const char *e4 = std::getenv("RWR_ONE_PIXEL_PER_LANE")) ctx->force_one_pixel = std::atoi(e4) != 0;
     if (const char *e5 = std::getenv("RWR_AUTO_BVH_FACE_PX")) ctx->auto_bvh_face_px = (float)std::atof(e5);
+    if (const char *e6 = std::getenv("RWR_WF_GROUP")) ctx->wf_group = std::min(kWfMaxGroup, std::max(1u, (uint32_t)std::strtoul(e6, nullptr, 10)));
+    if (const char *e7 = std::getenv("RWR_WF_PACKET_FILL")) ctx->wf_packet_fill = (float)std::atof(e7);
     if (const char *e3 = std::getenv("RWR_BIN_MIN_FACES")) ctx->bin_min_faces = (uint32_t)std::strtoul(e3, nullptr, 10);
     *out_ctx = ctx;
     return RWR_OK;
@@ -461,7 +470,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
     ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
     ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
-    ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_seg_count.release(); ctx->d_seg_total.release(); for (auto &t : ctx->d_texs) t.release();
+    ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wave_total.release(); for (auto &t : ctx->d_texs) t.release();
     ctx->d_face_mat.release(); ctx->d_materials.release();
     for (FrameSlot &sl : ctx->slots) {
         sl.release_buffers();
@@ -471,6 +480,8 @@ void rwr_ctx_destroy(rwr_context *ctx)
     for (hipEvent_t e : ctx->timing_events) (void)hipEventDestroy(e);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->probe_stream) { (void)hipStreamSynchronize(ctx->probe_stream); (void)hipStreamDestroy(ctx->probe_stream); }
+    ctx->d_probe.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -823,30 +834,35 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
                                             dispatch_timed ? ctx->timing_events[2 * ctx->timing_pairs + 1] : nullptr));
         ctx->last_spp = 0;
     } else {
-        // wavefront integrator: per sample pass, primary stage then (queue-driven) bounce stage
-        // one 256-slot queue segment per workgroup (32x8 pixels) of the primary stage
-        const uint32_t n_segments = ((ctx->screen.width + 31u) / 32u) * ((row_end - row_begin + 7u) / 8u);
+        // wavefront integrator: the samples are traced in launch groups; per group the primary stage (all of the
+        // group's samples of every pixel, rays into the fixed-slot queue) then the bounce stage (one workgroup per
+        // 64x8-pixel tile and its ray pool)
+        const uint32_t group = std::min(rp.spp, ctx->wf_group);
+        const uint32_t tiles_x = (ctx->screen.width + kWfTileW - 1u) / kWfTileW, tiles_y = (row_end - row_begin + kWfTileH - 1u) / kWfTileH;
+        const uint32_t n_tiles = tiles_x * tiles_y;
         RWR_HIP_CHECK(ctx->d_accum.ensure(n));
-        RWR_HIP_CHECK(ctx->d_seg_count.ensure(n_segments));
-        RWR_HIP_CHECK(ctx->d_seg_total.ensure(n_segments));
+        RWR_HIP_CHECK(ctx->d_wave_total.ensure((size_t)n_tiles * 4u));
         if (rp.max_bounces) {
-            RWR_HIP_CHECK(ctx->d_q0.ensure((size_t)n_segments * 256));
-            RWR_HIP_CHECK(ctx->d_q1.ensure((size_t)n_segments * 256));
-            RWR_HIP_CHECK(ctx->d_q2.ensure((size_t)n_segments * 256));
+            const size_t slots = (size_t)n_tiles * group * kWfTilePixels;
+            RWR_HIP_CHECK(ctx->d_q0.ensure(slots));
+            RWR_HIP_CHECK(ctx->d_q1.ensure(slots));
+            RWR_HIP_CHECK(ctx->d_q2.ensure(slots));
+            RWR_HIP_CHECK(ctx->d_wf_sorted.ensure(slots));
+            RWR_HIP_CHECK(ctx->d_wf_masks.ensure((size_t)n_tiles * group * 8u));
         }
-        const WfBuffers wf{ctx->d_accum.ptr, ctx->d_q0.ptr, ctx->d_q1.ptr, ctx->d_q2.ptr, ctx->d_seg_count.ptr, ctx->d_seg_total.ptr};
+        const WfBuffers wf{ctx->d_accum.ptr, ctx->d_q0.ptr, ctx->d_q1.ptr, ctx->d_q2.ptr, ctx->d_wf_masks.ptr, ctx->d_wf_sorted.ptr,
+                           ctx->d_wave_total.ptr, group, tiles_x};
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
-        for (uint32_t sidx = 0; sidx < rp.spp; sidx++) {
-            fp.sample = sidx;
-            RWR_HIP_CHECK(launch_wf_primary(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0,
-                                            tg, wf));
+        for (uint32_t s0 = 0; s0 < rp.spp; s0 += group) {
+            const uint32_t cnt = std::min(group, rp.spp - s0);
+            RWR_HIP_CHECK(launch_wf_primary(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0, tg, wf, s0, cnt));
             if (rp.max_bounces)
-                RWR_HIP_CHECK(launch_wf_bounce(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh, tex0,
-                                               wf, n_segments));
+                RWR_HIP_CHECK(launch_wf_bounce(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh, tex0, wf, n_tiles, cnt,
+                                               (uint32_t)std::fmax(1.0f, std::ceil(ctx->wf_packet_fill * (float)(cnt * kWfTilePixels)))));
         }
         RWR_HIP_CHECK(launch_wf_resolve(stream, fp, tg, wf));
         ctx->last_spp = rp.spp;
-        ctx->last_segments = n_segments;
+        ctx->last_segments = n_tiles;
         ctx->last_had_bounce = rp.max_bounces != 0;
     }
     if (time_this) {
@@ -1004,29 +1020,59 @@ int rwr_measure_valu_clock(rwr_context *ctx, uint32_t waves_per_simd, double out
     const uint32_t n_wg = (uint32_t)prop.multiProcessorCount * waves_per_simd, n_waves = n_wg * 4u, iters = 1u << 15;
     struct Scoped {
         DeviceBuffer<ulonglong2> b;
-        ~Scoped() { b.release(); }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Scoped() { b.release(); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
     } scoped;
     RWR_HIP_CHECK(scoped.b.ensure(n_waves));
+    RWR_HIP_CHECK(hipEventCreate(&scoped.e0));
+    RWR_HIP_CHECK(hipEventCreate(&scoped.e1));
     std::vector<ulonglong2> h(n_waves);
     RWR_HIP_CHECK(sync_all(ctx));
     for (int mode = 0; mode < 2; mode++) {
         // an untimed launch first: the stamped one then starts on a busy, clocked-up chip
         RWR_HIP_CHECK(launch_measure_valu(ctx->stream, mode, scoped.b.ptr, n_wg, iters));
+        RWR_HIP_CHECK(hipEventRecord(scoped.e0, ctx->stream));
         RWR_HIP_CHECK(launch_measure_valu(ctx->stream, mode, scoped.b.ptr, n_wg, iters));
+        RWR_HIP_CHECK(hipEventRecord(scoped.e1, ctx->stream));
         RWR_HIP_CHECK(hipMemcpyAsync(h.data(), scoped.b.ptr, n_waves * sizeof(ulonglong2), hipMemcpyDeviceToHost, ctx->stream));
         RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        std::vector<double> cyc(n_waves), mhz(n_waves);
-        for (uint32_t i = 0; i < n_waves; i++) {
-            cyc[i] = (double)h[i].x;
-            mhz[i] = h[i].y ? (double)h[i].x / (double)h[i].y * 100.0 : 0.0;
-        }
-        std::nth_element(cyc.begin(), cyc.begin() + n_waves / 2, cyc.end());
+        float ms = 0.0f;
+        RWR_HIP_CHECK(hipEventElapsedTime(&ms, scoped.e0, scoped.e1));
+        std::vector<double> mhz(n_waves);
+        for (uint32_t i = 0; i < n_waves; i++) mhz[i] = h[i].y ? (double)h[i].x / (double)h[i].y * 100.0 : 0.0;
         std::nth_element(mhz.begin(), mhz.begin() + n_waves / 2, mhz.end());
-        // every SIMD issued waves_per_simd * iters * 8 wave instructions while a wave's stamps were apart
-        const double per_instr = cyc[n_waves / 2] / ((double)waves_per_simd * iters * 8.0);
-        if (mode == 0) { out4[0] = mhz[n_waves / 2]; out4[1] = per_instr; }
-        else { out4[2] = per_instr; out4[3] = mhz[n_waves / 2]; }
+        const double clock_mhz = mhz[n_waves / 2];
+        // every SIMD issued (waves on it) * iters * 8 wave instructions during the launch (HIP events around it);
+        // cycles = elapsed time x the in-kernel clock
+        const double instr_per_simd = (double)n_waves / (4.0 * prop.multiProcessorCount) * iters * 8.0;
+        const double per_instr = (double)ms * 1e-3 * clock_mhz * 1e6 / instr_per_simd;
+        if (mode == 0) { out4[0] = clock_mhz; out4[1] = per_instr; }
+        else { out4[2] = per_instr; out4[3] = clock_mhz; }
     }
+    return RWR_OK;
+}
+
+int rwr_clock_probe_start(rwr_context *ctx, uint32_t micros)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (micros == 0u || micros > 100000u) return set_error(RWR_ERR_INVALID_ARGUMENT, "probe duration must be 1..100000 us");
+    DeviceGuard g(ctx->device);
+    if (!ctx->probe_stream) RWR_HIP_CHECK(hipStreamCreateWithFlags(&ctx->probe_stream, hipStreamNonBlocking));
+    RWR_HIP_CHECK(ctx->d_probe.ensure(1));
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->probe_stream));
+    RWR_HIP_CHECK(launch_clock_probe(ctx->probe_stream, ctx->d_probe.ptr, micros * 100u));
+    return RWR_OK;
+}
+
+int rwr_clock_probe_read(rwr_context *ctx, double *shader_mhz)
+{
+    if (!ctx || !shader_mhz) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!ctx->probe_stream) return set_error(RWR_ERR_NOT_READY, "rwr_clock_probe_start has not been called");
+    DeviceGuard g(ctx->device);
+    ulonglong2 h{0, 0};
+    RWR_HIP_CHECK(hipMemcpyAsync(&h, ctx->d_probe.ptr, sizeof h, hipMemcpyDeviceToHost, ctx->probe_stream));
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->probe_stream));
+    *shader_mhz = h.y ? (double)h.x / (double)h.y * 100.0 : 0.0;
     return RWR_OK;
 }
 
@@ -1035,9 +1081,9 @@ int rwr_last_render_stats(rwr_context *ctx, uint64_t *primary_rays, uint64_t *bo
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (ctx->last_spp && ctx->last_had_bounce) {
         DeviceGuard g(ctx->device);
-        std::vector<uint32_t> counts(ctx->last_segments);
+        std::vector<uint32_t> counts((size_t)ctx->last_segments * 4u);   // per tile and wave of the primary stage
         RWR_HIP_CHECK(hipStreamSynchronize(ctx->slots[ctx->cur].stream));
-        RWR_HIP_CHECK(hipMemcpy(counts.data(), ctx->d_seg_total.ptr, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        RWR_HIP_CHECK(hipMemcpy(counts.data(), ctx->d_wave_total.ptr, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         ctx->last_bounce = 0;
         for (uint32_t c : counts) ctx->last_bounce += c;
     }

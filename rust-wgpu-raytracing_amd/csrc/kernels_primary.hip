@@ -65,7 +65,8 @@ k_prebake(const rwr_model_vertex_small *__restrict__ verts, const rwr_model_face
     T.e0[0] = v0v1.x; T.e0[1] = v0v1.y; T.e0[2] = v0v1.z; T.pad2 = 0.0f;
     T.e1[0] = e1.x; T.e1[1] = e1.y; T.e1[2] = e1.z; T.pad3 = 0.0f;
     T.e2[0] = e2.x; T.e2[1] = e2.y; T.e2[2] = e2.z; T.pad4 = 0.0f;
-    T.pad5[0] = T.pad5[1] = T.pad5[2] = T.pad5[3] = 0.0f;
+    const f3 nh = normalize3(N);   // literal f32 (IEEE sqrt / divide in this translation unit)
+    T.nhat[0] = nh.x; T.nhat[1] = nh.y; T.nhat[2] = nh.z; T.pad5 = 0.0f;
     tris[i] = T;
     // Shading record (colour path): the face-only part of compute.wgsl:217-234 in double, rounded once.
     // A degenerate face (N = 0) gets non-finite values and can never be hit (:94).
@@ -274,6 +275,8 @@ hipError_t preload_kernels()
     hipError_t e = preload_kernels_primary();
     if (e == hipSuccess) e = preload_kernels_primary_p2();
     if (e == hipSuccess) e = preload_kernels_wavefront();
+    if (e == hipSuccess) e = preload_kernels_wf_primary();
+    if (e == hipSuccess) e = preload_kernels_wf_bounce();
     return e;
 }
 

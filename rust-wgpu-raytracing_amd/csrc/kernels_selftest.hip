@@ -106,6 +106,29 @@ k_measure_valu(ulonglong2 *out, uint32_t iters, float s)
         out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = make_ulonglong2(c1 - c0, r1 - r0);
 }
 
+// One wave that does nothing but watch the two counters for `ticks` ticks of the 100 MHz counter: launched on a
+// side stream while frames render, it reports the shader clock the chip runs at UNDER THAT WORKLOAD (a pure FMA
+// loop pulls the clock lower than the frame kernel does).
+__global__ void __launch_bounds__(64)
+k_clock_probe(ulonglong2 *out, uint32_t ticks)
+{
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    uint64_t r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const uint64_t c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) out[0] = make_ulonglong2(c1 - c0, r1 - r0);
+}
+
+hipError_t launch_clock_probe(hipStream_t s, ulonglong2 *d_out, uint32_t ticks)
+{
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, d_out, ticks);
+    return hipGetLastError();
+}
+
 hipError_t launch_measure_valu(hipStream_t s, int mode, ulonglong2 *d_out, uint32_t n_workgroups, uint32_t iters)
 {
     if (mode == 0) hipLaunchKernelGGL((k_measure_valu<0>), dim3(n_workgroups), dim3(256), 0, s, d_out, iters, 1.0001f);

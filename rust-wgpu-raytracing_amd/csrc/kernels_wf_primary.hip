@@ -1,0 +1,378 @@
+// Wavefront integrator, first stage (extension; BASELINE.json configs 2-4 — the reference traces one centre
+// ray per pixel and has no samples or bounces; specification: DESIGN.md "Extended integrator",
+// restated brute force in oracle/rt_oracle.c or_render_path).
+//
+//   k_wf_primary   ONE launch traces a whole GROUP of samples (up to 32) of every pixel.  Same mapping as the
+//                  fused frame kernel (kernels_primary_p2.hip): wave64 = 32x4-pixel tile, two horizontally
+//                  adjacent pixels per lane (v_pk_* arithmetic), per-wave culling against the per-frame
+//                  FrameTri records, face records in scalar registers, no LDS, no barrier.  Per sample: jittered
+//                  ray (counter-based RNG keyed by GLOBAL pixel, sample, seed), spheres + mesh with the
+//                  reference's depth compositing, local shading E(h0); the group's E(h0) are summed in
+//                  registers in sample order and the RGBA32F accumulator is read and written ONCE per group
+//                  (16 + 16 B per pixel per group instead of per sample).  A pixel that hit a surface builds
+//                  its cosine-distributed bounce ray and stores it at its FIXED slot of the ray queue in HBM
+//                  (coalesced 16-byte stores, rwr_internal.h WfBuffers); the wave publishes the ballot of the
+//                  lanes that emitted.  Compaction — ballot + prefix popcount — happens in the consumer
+//                  (kernels_wf_bounce.hip), folded into the sort of the tile's ray pool by direction.
+//                  Rays that left the scene cost nothing downstream.
+//
+// Everything that decides what a sample sees (ray, hit tests, selection, depth, bounce ray) is written operation
+// for operation like the oracle, so sample-0 planes are bit-exact and every bounce ray is the oracle's.
+#include <hip/hip_ext.h>
+
+#include "rwr_primary.h"
+#include "rwr_shade_p2.h"
+
+namespace rwr {
+
+// rng_hash (rwr_device.h) in two steps: everything up to the dimension is shared by the uniforms of one
+// (pixel, sample).  rng_dim(rng_base(pixel, sample, seed), dim) == rng_hash(pixel, sample, dim, seed).
+RWR_DEV uint32_t rng_base(uint32_t pixel, uint32_t sample, uint32_t seed)
+{
+    uint32_t h = seed ^ 0x9E3779B9u;
+    h = rng_mix(h ^ pixel);
+    return rng_mix(h ^ (sample * 0x85EBCA6Bu));
+}
+RWR_DEV float rng_dim(uint32_t base, uint32_t dim)
+{
+    return (float)(rng_mix(base ^ (dim * 0xC2B2AE35u)) >> 8) * (1.0f / 16777216.0f);
+}
+
+// n / d for a wave-uniform positive integer-valued d (the frame's width or height) and 0 <= n < 2^16: the
+// compiler's IEEE expansion of the quotient with the reciprocal refined once per wave and the instructions that
+// are the identity on such operands left out (rwr_device.h div_shared_rcp; zero numerators give +0 either way).
+RWR_DEV float refined_rcp(float d)
+{
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+
+// pixelToRay (compute.wgsl:150-164) for the pixel-space points (fx.x, fy.x) and (fx.y, fy.y).
+RWR_DEV v3 pixel_pair_ray_dir_at(const rwr_camera_inv_uniform &cam, f2 fx, f2 fy, float width, float height, float rw, float rh)
+{
+    const f2 x_nds = div_shared_rcp(2.0f * fx, splat(width), splat(rw)) - 1.0f;
+    const f2 y_nds = div_shared_rcp(2.0f * fy, splat(height), splat(rh)) - 1.0f;
+    const float(&p)[4][4] = cam.proj_inv;
+    const f2 vx = p[0][0] * x_nds + p[1][0] * y_nds + p[2][0] * 1.0f + p[3][0] * 1.0f;
+    const f2 vy = p[0][1] * x_nds + p[1][1] * y_nds + p[2][1] * 1.0f + p[3][1] * 1.0f;
+    const f2 vz = p[0][2] * x_nds + p[1][2] * y_nds + p[2][2] * 1.0f + p[3][2] * 1.0f;
+    const f2 vw = splat(0.0f);
+    const float(&m)[4][4] = cam.viewmodel_inv;
+    v3 w;
+    w.x = m[0][0] * vx + m[1][0] * vy + m[2][0] * vz + m[3][0] * vw;
+    w.y = m[0][1] * vx + m[1][1] * vy + m[2][1] * vz + m[3][1] * vw;
+    w.z = m[0][2] * vx + m[1][2] * vy + m[2][2] * vz + m[3][2] * vw;
+    if (__all(normalize_fast_domain(w))) return normalize3_fast(w);
+    return normalize3(w);
+}
+
+// bounce_direction (rwr_device.h) for a pixel pair; lanes / elements whose `want` is 0 still compute (cheaply
+// wrong values are never stored).  base: rng_base of each pixel for this sample.
+RWR_DEV v3 bounce_direction_pair(v3 n, u2 base, i2 want)
+{
+    // Rejection-sample the unit disk (up to 8 tries per pixel, a = b = 0 when all fail).  78.5 % of the tries
+    // succeed: the first try runs for both pixels at once; for the rest a lane takes ONE try of ONE pixel per
+    // iteration (first its left pixel's, then its right pixel's), so a wave iterates max over lanes of the tries
+    // both pixels still need, not 2 x max over pixels.
+    f2 a = splat(0.0f), b = splat(0.0f);
+    i2 need = want;
+    {
+        const f2 ua = 2.0f * f2{rng_dim(base.x, 2u), rng_dim(base.y, 2u)} - 1.0f;
+        const f2 ub = 2.0f * f2{rng_dim(base.x, 3u), rng_dim(base.y, 3u)} - 1.0f;
+        const i2 ok = need & ((ua * ua + ub * ub) <= 1.0f);
+        a = ok ? ua : a;
+        b = ok ? ub : b;
+        need &= ~ok;
+    }
+    bool busy = any2(need);
+    uint32_t sel = need.x ? 0u : 1u, k = 1u;
+    while (__any(busy)) {
+        if (busy) {
+            const uint32_t bs = sel ? base.y : base.x;
+            const float ua = 2.0f * rng_dim(bs, 2u + 2u * k) - 1.0f;
+            const float ub = 2.0f * rng_dim(bs, 3u + 2u * k) - 1.0f;
+            const bool ok = (ua * ua + ub * ub) <= 1.0f;
+            if (ok) {
+                if (sel) { a.y = ua; b.y = ub; } else { a.x = ua; b.x = ub; }
+            }
+            if (ok || k == 7u) {          // this pixel is done: on to the lane's other pixel, or out
+                if (sel == 0u && need.y) { sel = 1u; k = 1u; }
+                else busy = false;
+            } else {
+                k++;
+            }
+        }
+    }
+    const f2 rad = 1.0f - a * a - b * b;
+    const f2 clamped = f2{fmaxf(0.0f, rad.x), fmaxf(0.0f, rad.y)};
+    // sqrt_fast returns sqrtf's bits on [2^-100, 2^100] (rwr_device.h); 0 and the rare tiny radicand take the long form
+    const bool sq_fast = __all(clamped.x >= 0x1p-100f && clamped.y >= 0x1p-100f);
+    const f2 dz = sq_fast ? sqrt_fast(clamped) : sqrt2(clamped);
+    const f2 sign = f2{copysignf(1.0f, n.z.x), copysignf(1.0f, n.z.y)};
+    const f2 aa = -1.0f / (sign + n.z);
+    const f2 bb = n.x * n.y * aa;
+    const v3 b1 = v3{1.0f + sign * n.x * n.x * aa, sign * bb, -sign * n.x};
+    const v3 b2 = v3{bb, sign + n.y * n.y * aa, -n.y};
+    v3 d = v3{a * b1.x + b * b2.x + dz * n.x, a * b1.y + b * b2.y + dz * n.y, a * b1.z + b * b2.z + dz * n.z};
+    // elements nobody wants get a harmless in-domain vector, so that they do not push the wave onto the long form
+    d.x = want ? d.x : splat(1.0f); d.y = want ? d.y : splat(1.0f); d.z = want ? d.z : splat(1.0f);
+    if (__all(normalize_fast_domain(d))) return normalize3_fast(d);
+    return normalize3(d);
+}
+
+#ifndef RWR_WF_OCC
+#define RWR_WF_OCC 4
+#endif
+template <bool AUX, bool CULL>
+__global__ void __launch_bounds__(256, AUX ? 3 : RWR_WF_OCC)
+k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_begin, uint32_t bins_enabled,
+             int32_t mesh_x0, int32_t mesh_y0, int32_t mesh_x1, int32_t mesh_y1, uint32_t sample_begin, uint32_t sample_count,
+             const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
+             const float4 *__restrict__ tex, const Targets tg, const WfBuffers wf)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t blk_x0 = blockIdx.x * kWfTileW;
+    const uint32_t tile_x0 = blk_x0 + (wave & 1u) * 32u;
+    const uint32_t tile_y0 = row_begin + blockIdx.y * kWfTileH + (wave >> 1) * 4u;
+    const uint32_t px0 = tile_x0 + 2u * (lane & 15u), py = tile_y0 + (lane >> 4);
+    constexpr float kTileWf = 32.0f, kTileHf = 4.0f;
+    const bool in0 = py < p.row_end && px0 < p.width, in1 = in0 && (px0 + 1u < p.width);
+    const uint32_t pix0 = py * p.width + px0;  // GLOBAL pixel index: RNG key and accumulator slot (< 2^30, rwr_resize)
+    const uint32_t tile = blockIdx.y * wf.tiles_x + blockIdx.x;
+
+    // source of candidate faces: the whole scene, or this tile's screen bin (shared by all samples of the frame)
+    uint32_t n_src = n_tris;
+    const uint32_t *__restrict__ src = nullptr;
+    if (CULL && bins_enabled) {
+        const uint32_t bin = ((tile_y0 - row_begin) / kBinH) * p.bins.bins_x + blk_x0 / kBinW;
+        n_src = p.bins.counts[bin];
+        src = p.bins.lists + (size_t)bin * p.bins.cap;
+    }
+    n_src = __builtin_amdgcn_readfirstlane(n_src);
+    if (CULL) {  // the tile lies outside the screen rectangle of the whole mesh
+        const int32_t wu = __builtin_amdgcn_readfirstlane((int32_t)wave);
+        const int32_t sx0 = (int32_t)blk_x0 + (wu & 1) * 32, sy0 = (int32_t)(row_begin + blockIdx.y * kWfTileH) + (wu >> 1) * 4;
+        if (sx0 + 32 < mesh_x0 || sx0 > mesh_x1 || sy0 + 4 < mesh_y0 || sy0 > mesh_y1) n_src = 0u;
+    }
+    const float tx0 = (float)tile_x0, ty0 = (float)tile_y0;
+    const TileRect tile_rect = {tx0, ty0, tx0 + kTileWf, ty0 + kTileHf};
+    // Jitter keeps a sample inside its pixel, so the tile's candidate faces are the same for every sample: up to 128
+    // source faces are culled once (two ballots, the face of each bit in a VGPR); longer lists are re-culled per sample.
+    const bool cached = n_src <= 128u;
+    unsigned long long cm0 = 0ull, cm1 = 0ull;
+    uint32_t cf0 = lane, cf1 = 64u + lane;
+    if (cached) {
+        bool keep = lane < n_src;
+        cf0 = (keep && src) ? src[lane] : lane;
+        if (CULL && keep) keep = !rect_culls(ftris[cf0], tile_rect);
+        cm0 = __ballot(keep);
+        keep = 64u + lane < n_src;
+        cf1 = (keep && src) ? src[64u + lane] : 64u + lane;
+        if (CULL && keep) keep = !rect_culls(ftris[cf1], tile_rect);
+        cm1 = __ballot(keep);
+    }
+    const float fw = (float)p.width, fh = (float)p.height;
+    const float rw = refined_rcp(fw), rh = refined_rcp(fh);
+    const f3 O = ld3(p.cam.origin);
+
+    f2 ar = splat(0.0f), ag = splat(0.0f), ab = splat(0.0f), aa = splat(0.0f);  // the group's sum of E(h0), alpha
+    uint32_t emitted = 0;  // rays this wave emitted in this launch (wave-uniform)
+
+    for (uint32_t sidx = 0; sidx < sample_count; sidx++) {
+        const uint32_t sample = sample_begin + sidx;
+        // -- the sample's ray: pixel centre at spp = 1, else two uniforms of the counter-based RNG ---------------
+        const u2 base = u2{rng_base(pix0, sample, p.seed), rng_base(pix0 + 1u, sample, p.seed)};
+        f2 jx = splat(0.5f), jy = splat(0.5f);
+        if (p.spp > 1u) {
+            jx = f2{rng_dim(base.x, 0u), rng_dim(base.y, 0u)};
+            jy = f2{rng_dim(base.x, 1u), rng_dim(base.y, 1u)};
+        }
+        const f2 fx = f2{(float)px0, (float)(px0 + 1u)} + jx;
+        const f2 fy = splat((float)py) + jy;
+        const v3 D = pixel_pair_ray_dir_at(p.cam, fx, fy, fw, fh, rw, rh);
+
+        f2 depth_tex = splat(0.0f), win_t = splat(0.0f);
+        i2 obj = i2{-1, -1};
+        // -- analytic sphere passes, in order (lib.rs:1106-1173) ------------------------------------------------
+        for (uint32_t s = 0; s < p.n_spheres; s++) {
+            if (CULL && ((tx0 + kTileWf < p.sphere_rect[s][0]) || (tx0 > p.sphere_rect[s][2]) ||
+                         (ty0 + kTileHf < p.sphere_rect[s][1]) || (ty0 > p.sphere_rect[s][3])))
+                continue;
+            f2 t = splat(0.0f);
+            const i2 hit = sphere_ray_intersect_t(ld3(p.spheres[s].center), p.spheres[s].radius, O, D, t);
+            if (any2(hit)) {
+                const f2 current_depth = 1.0f - depth_tex;  // sphere/compute.wgsl:130
+                const f2 depth = to_non_linear_depth(t);
+                const i2 win = hit & ~(depth >= current_depth);
+                depth_tex = win ? (1.0f - depth) : depth_tex;
+                obj = win ? i2{-2 - (int)s, -2 - (int)s} : obj;
+                win_t = win ? t : win_t;
+            }
+        }
+        // -- mesh pass (lib.rs:1174-1184): per-wave culling, survivors in ascending face order ------------------
+        MeshHit2 best;
+        best.have = i2{0, 0};
+        best.t = best.u = best.v = best.ndotd = splat(0.0f);
+        best.idx = u2{0u, 0u};
+        uint32_t n_tested = 0;
+        ShadeRec last_shade = {};
+        // survivors in ascending face order; wave-uniform face index: the record comes in through scalar loads.
+        // Samples jitter the ray, never the origin: the plane numerator is the frame's per-face table.
+        auto walk = [&](unsigned long long m, uint32_t faces_v) {
+            while (m) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)faces_v, (int)b);
+                intersect_and_select(tris[idx], p.tnum[idx], idx, O, D, best);
+                n_tested++;
+                last_shade = shade[idx];
+            }
+        };
+        if (cached) {
+            walk(cm0, cf0);
+            walk(cm1, cf1);
+        } else {
+            for (uint32_t base_f = 0; base_f < n_src; base_f += 64u) {
+                const uint32_t e = base_f + lane;
+                bool keep = e < n_src;
+                const uint32_t my_face = (keep && src) ? src[e] : e;
+                if (CULL && keep) keep = !rect_culls(ftris[my_face], tile_rect);
+                walk(__ballot(keep), my_face);
+            }
+        }
+        if (any2(best.have)) {
+            const f2 current_depth = 1.0f - depth_tex;  // compute.wgsl:210
+            const bool fast = !__any(any2(best.have & ~depth_fast_domain(best.t)));
+            const f2 depth = fast ? to_non_linear_depth_fast(best.t) : to_non_linear_depth(best.t);
+            const i2 win = best.have & ~(depth >= current_depth);
+            depth_tex = win ? (1.0f - depth) : depth_tex;
+            obj = win ? i2{(int)best.idx.x, (int)best.idx.y} : obj;
+            win_t = win ? best.t : win_t;
+        }
+        if (sample == 0u && in0) {  // depth / aux planes report sample 0
+            tg.depth[pix0] = depth_tex.x;
+            if (AUX) { tg.obj_id[pix0] = obj.x; tg.hit_t[pix0] = win_t.x; }
+            if (in1) {
+                tg.depth[pix0 + 1u] = depth_tex.y;
+                if (AUX) { tg.obj_id[pix0 + 1u] = obj.y; tg.hit_t[pix0 + 1u] = win_t.y; }
+            }
+        }
+
+        // -- local shading E(h0) and the surface's albedo ----------------------------------------------------------
+        f2 cr = splat(0.0f), cg = splat(0.0f), cb = splat(0.0f);
+        f2 tr = splat(0.0f), tgc = splat(0.0f), tb = splat(0.0f);
+        if (__any(any2(obj >= 0))) {
+            f2 mr, mg, mb, xr, xg, xb;
+            if (p.n_materials > 1u) shade_mesh_pair<true, false>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
+            else if (n_tested == 1u) shade_mesh_pair<false, true>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
+            else shade_mesh_pair<false, false>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
+            const i2 is_mesh = obj >= 0;
+            cr = is_mesh ? mr : cr; cg = is_mesh ? mg : cg; cb = is_mesh ? mb : cb;
+            tr = is_mesh ? xr : tr; tgc = is_mesh ? xg : tgc; tb = is_mesh ? xb : tb;
+        }
+        v3 n;  // the surface normal as the reference's HitRecord holds it (exact: it steers the bounce)
+        n.x = n.y = splat(0.0f); n.z = splat(1.0f);
+        if (__any(any2(obj < -1))) {  // sphere winners (few tiles): one pixel at a time
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int o = k ? obj.y : obj.x;
+                if (o < -1) {
+                    const f3 Dk = lane3(D, k);
+                    const f3 center = ld3(p.spheres[-2 - o].center);
+                    const f3 P = along(O, k ? win_t.y : win_t.x, Dk);
+                    const f3 c = shade_sphere(cnormalize(sub3(P, center)), Dk);
+                    const f3 ne = normalize3(sub3(P, center));
+                    if (k) { cr.y = c.x; cg.y = c.y; cb.y = c.z; tr.y = 1.0f; tgc.y = 0.0f; tb.y = 0.0f; n.x.y = ne.x; n.y.y = ne.y; n.z.y = ne.z; }
+                    else { cr.x = c.x; cg.x = c.y; cb.x = c.z; tr.x = 1.0f; tgc.x = 0.0f; tb.x = 0.0f; n.x.x = ne.x; n.y.x = ne.y; n.z.x = ne.z; }
+                }
+            }
+        }
+        const i2 hit = obj != -1;
+        ar += hit ? cr : splat(0.0f); ag += hit ? cg : splat(0.0f); ab += hit ? cb : splat(0.0f);
+        aa += hit ? splat(2.0f) : splat(0.0f);   // alpha 1 + 1 on a written pixel (compute.wgsl:231-234)
+
+        // -- bounce ray of every pixel that hit something ----------------------------------------------------------
+        if (p.bounces != 0u) {
+            const i2 emit = hit & i2{in0 ? -1 : 0, in1 ? -1 : 0};
+            const unsigned long long m0 = __ballot(emit.x != 0), m1 = __ballot(emit.y != 0);
+            const uint32_t slot_base = (tile * wf.group + sidx) * kWfTilePixels + wave * 128u;
+            if (lane == 0u) {
+                unsigned long long *mk = wf.masks + (size_t)(tile * wf.group + sidx) * 8u + wave * 2u;
+                mk[0] = m0; mk[1] = m1;
+            }
+            emitted += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+            if (m0 | m1) {
+                // mesh winners: +-normalize(N), prebaked with the shader's own operations (TriRecord::nhat)
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int o = k ? obj.y : obj.x;
+                    if (o >= 0) {
+                        f3 nh = ld3(tris[o].nhat);
+                        if ((k ? best.ndotd.y : best.ndotd.x) > 0.0f) nh = neg3(nh);   // compute.wgsl:140-142
+                        if (k) { n.x.y = nh.x; n.y.y = nh.y; n.z.y = nh.z; } else { n.x.x = nh.x; n.y.x = nh.y; n.z.x = nh.z; }
+                    }
+                }
+                const v3 P = along(splat3(O), win_t, D);
+                const v3 O1 = v3{P.x + n.x * 1e-4f, P.y + n.y * 1e-4f, P.z + n.z * 1e-4f};
+                const v3 D1 = bounce_direction_pair(n, base, emit);
+                if (emit.x) {
+                    const uint32_t slot = slot_base + lane;
+                    wf.q0[slot] = make_float4(O1.x.x, O1.y.x, O1.z.x, tr.x);
+                    wf.q1[slot] = make_float4(D1.x.x, D1.y.x, D1.z.x, tgc.x);
+                    wf.q2[slot] = tb.x;
+                }
+                if (emit.y) {
+                    const uint32_t slot = slot_base + 64u + lane;
+                    wf.q0[slot] = make_float4(O1.x.y, O1.y.y, O1.z.y, tr.y);
+                    wf.q1[slot] = make_float4(D1.x.y, D1.y.y, D1.z.y, tgc.y);
+                    wf.q2[slot] = tb.y;
+                }
+            }
+        }
+    }
+
+    // -- the accumulator: read and written once per group -----------------------------------------------------------
+    if (in0) {
+        float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0;
+        if (sample_begin != 0u) {
+            a0 = wf.accum[pix0];
+            if (in1) a1 = wf.accum[pix0 + 1u];
+        }
+        a0.x += ar.x; a0.y += ag.x; a0.z += ab.x; a0.w += aa.x;
+        wf.accum[pix0] = a0;
+        if (in1) {
+            a1.x += ar.y; a1.y += ag.y; a1.z += ab.y; a1.w += aa.y;
+            wf.accum[pix0 + 1u] = a1;
+        }
+    }
+    if (lane == 0u) {
+        uint32_t *wt = wf.wave_total + tile * 4u + wave;
+        *wt = (sample_begin == 0u ? 0u : *wt) + emitted;
+    }
+}
+
+hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
+                             const FrameTri *ftris, const float4 *tex, const Targets &tg, const WfBuffers &wf,
+                             uint32_t sample_begin, uint32_t sample_count)
+{
+    if (fp.row_end <= fp.row_begin || fp.width == 0 || sample_count == 0) return hipSuccess;
+    const dim3 grid((fp.width + kWfTileW - 1u) / kWfTileW, (fp.row_end - fp.row_begin + kWfTileH - 1u) / kWfTileH);
+    const dim3 block(256);
+    const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0, do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
+#define RWR_WF_ARGS ftris, fp.n_tris, fp.row_begin, fp.bins.enabled, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], \
+                    sample_begin, sample_count, fp, tris, shade, tex, tg, wf
+    if (aux && do_cull) hipLaunchKernelGGL((k_wf_primary<true, true>), grid, block, 0, s, RWR_WF_ARGS);
+    else if (aux) hipLaunchKernelGGL((k_wf_primary<true, false>), grid, block, 0, s, RWR_WF_ARGS);
+    else if (do_cull) hipLaunchKernelGGL((k_wf_primary<false, true>), grid, block, 0, s, RWR_WF_ARGS);
+    else hipLaunchKernelGGL((k_wf_primary<false, false>), grid, block, 0, s, RWR_WF_ARGS);
+#undef RWR_WF_ARGS
+    return hipGetLastError();
+}
+
+hipError_t preload_kernels_wf_primary()
+{
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((&k_wf_primary<false, true>)));
+}
+
+}  // namespace rwr

@@ -33,7 +33,8 @@ struct alignas(16) TriRecord {
     float e0[3]; float pad2;   // p1 - p0                              compute.wgsl:115
     float e1[3]; float pad3;   // p2 - p1                              compute.wgsl:123
     float e2[3]; float pad4;   // p0 - p2                              compute.wgsl:132
-    float pad5[4];
+    float nhat[3]; float pad5; // normalize(N), literal f32 operations (compute.wgsl:142 before the flip of :140):
+                               // the extended integrator's bounce rays start from it (normalize(-N) == -normalize(N) exactly)
 };
 static_assert(sizeof(TriRecord) == 128, "TriRecord is 128 B");
 
@@ -167,15 +168,25 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, const rwr_model_face_small *faces,
                           const uint32_t *face_material, uint32_t n_faces, const rwr_instance_raw *instances,
                           uint32_t n_instances, const MaterialRec *materials, TriRecord *tris, ShadeRec *shade, CullRec *cull);
-// Wavefront integrator state (kernels_wavefront.hip).  Ray queue = SoA in HBM, 40 B per
-// bounce ray: q0 = {O.xyz, pixel}, q1 = {D.xyz, thr.r}, q2 = {thr.g, thr.b}; workgroup w of
-// the primary stage owns slots [256 w, 256 w + seg_count[w]).
+// Wavefront integrator state (kernels_wf_primary.hip / kernels_wf_bounce.hip).  A launch group traces `group`
+// samples of every pixel.  A *tile* is the 64x8-pixel block of one workgroup of the primary stage (4 waves of
+// 32x4 pixels, two pixels per lane); its *pool* is the bounce rays those samples emit.  Ray queue = SoA in HBM,
+// 36 B per bounce ray, at FIXED slots
+//     slot = (tile * group + sample_in_group) * 512 + wave * 128 + k * 64 + lane        (k: which pixel of the lane)
+// q0 = {O.xyz, thr.r}, q1 = {D.xyz, thr.g}, q2 = thr.b; masks[(tile * group + s) * 8 + wave * 2 + k] = ballot of the
+// lanes that emitted.  The bounce stage compacts a pool by those ballots while sorting it by direction.
+constexpr uint32_t kWfTileW = 64, kWfTileH = 8, kWfTilePixels = kWfTileW * kWfTileH;
+constexpr uint32_t kWfMaxGroup = 32;          // samples per launch group (LDS of the bounce stage is sized for it)
+constexpr uint32_t kWfDirBins = 512;          // 8 octants x 8x8 cells of the octahedral map
 struct WfBuffers {
-    float4 *accum;        // W*H RGBA32F running sums (rgb = radiance, a = 2 * primary hits)
+    float4 *accum;                 // W*H RGBA32F running sums (rgb = radiance, a = 2 * primary hits)
     float4 *q0, *q1;
-    float2 *q2;
-    uint32_t *seg_count;  // per workgroup of k_wf_primary: rays in its 256-slot queue segment (this pass)
-    uint32_t *seg_total;  // per workgroup: bounce rays emitted over all passes of the frame
+    float *q2;
+    unsigned long long *masks;
+    uint16_t *sorted;              // per tile: group * 512 pool slots in direction order (scratch of the bounce stage)
+    uint32_t *wave_total;          // per tile and wave: bounce rays emitted over all groups of the frame
+    uint32_t group;                // samples per launch group this frame
+    uint32_t tiles_x;
 };
 struct BvhNode4;
 struct BvhDevice {
@@ -190,10 +201,10 @@ hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriReco
                              hipEvent_t ev_stop = nullptr);
 hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                              const FrameTri *ftris, const float4 *tex, const Targets &tg,
-                             const WfBuffers &wf);
+                             const WfBuffers &wf, uint32_t sample_begin, uint32_t sample_count);
 hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                             const BvhDevice &bvh, const float4 *tex, const WfBuffers &wf,
-                            uint32_t n_segments);
+                            uint32_t n_tiles, uint32_t sample_count, uint32_t packet_min_rays);
 hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                               const BvhDevice &bvh, const float4 *tex, const Targets &tg);
 hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf);
@@ -220,11 +231,14 @@ hipError_t preload_kernels();
 hipError_t preload_kernels_primary();
 hipError_t preload_kernels_primary_p2();
 hipError_t preload_kernels_wavefront();
+hipError_t preload_kernels_wf_primary();
+hipError_t preload_kernels_wf_bounce();
 
 // kernels_selftest.hip: out[0..3] += depth inputs compared, mismatches, normalize inputs compared, mismatches
 hipError_t launch_selftest_exact_math(hipStream_t s, unsigned long long *d_out4, uint32_t normalize_count, uint32_t seed);
 
 // kernels_selftest.hip: d_out[wave] = {shader cycles, 100 MHz ticks} around iters * 8 v_fma_f32 (mode 0) / v_pk_fma_f32 (mode 1)
+hipError_t launch_clock_probe(hipStream_t s, ulonglong2 *d_out, uint32_t ticks_100mhz);
 hipError_t launch_measure_valu(hipStream_t s, int mode, ulonglong2 *d_out, uint32_t n_workgroups, uint32_t iters);
 
 hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const rwr_camera_inv_uniform &cam, uint32_t width,
