@@ -38,6 +38,7 @@ struct Bvh {
     std::vector<BvhNode4> nodes;       // nodes[0] is the root (present even for 1 face)
     std::vector<uint32_t> leaf_faces;  // face indices, grouped per leaf, ascending inside a leaf
     uint32_t max_depth = 0;            // of the 4-wide tree
+    float mean_leaf_extent = 0.0f;     // mean over the leaves of the largest box dimension (the scale of the geometry)
 };
 
 namespace bvh_detail {
@@ -188,6 +189,17 @@ inline Bvh build_bvh(const float *tri, uint32_t n, uint32_t max_leaf = kBvhMaxLe
     b.nodes.reserve(2 * (size_t)n);
     const int root2 = b.build(0, n);
 
+    {
+        double sum = 0.0;
+        size_t n_leaves = 0;
+        for (const Node2 &nd : b.nodes)
+            if (nd.count) {
+                const float dx = nd.box.hi[0] - nd.box.lo[0], dy = nd.box.hi[1] - nd.box.lo[1], dz = nd.box.hi[2] - nd.box.lo[2];
+                const float ext = std::max(dx, std::max(dy, dz));
+                if (std::isfinite(ext)) { sum += ext; n_leaves++; }
+            }
+        out.mean_leaf_extent = n_leaves ? (float)(sum / (double)n_leaves) : 0.0f;
+    }
     // leaves: faces ascending inside a leaf (the tie rule is decided by index, order is cosmetic)
     out.leaf_faces = b.order;
     for (const Node2 &nd : b.nodes)

@@ -113,6 +113,8 @@ struct rwr_context {
     DeviceBuffer<BvhNode4> d_bvh_nodes;
     DeviceBuffer<uint32_t> d_bvh_leaf_faces;
     uint32_t bvh_n_nodes = 0, bvh_depth = 0;
+    float bvh_leaf_extent = 0.0f;
+    float wf_packet_extent = 0.5f;   // x mean leaf extent; tunable: RWR_WF_PACKET_EXTENT
     float aabb_lo[3] = {0, 0, 0}, aabb_hi[3] = {0, 0, 0};   // of the (flattened) world-space faces
     float auto_bvh_face_px = 150.0f;   // tunable: RWR_AUTO_BVH_FACE_PX (0 = never pick the BVH kernel by itself)
     // wavefront integrator state
@@ -121,9 +123,15 @@ struct rwr_context {
     DeviceBuffer<unsigned long long> d_wf_masks;
     DeviceBuffer<uint16_t> d_wf_sorted;
     DeviceBuffer<uint32_t> d_wave_total;
+    DeviceBuffer<unsigned long long> d_wf_fix;   // fixed-point bounce sums, 3 planes
+    DeviceBuffer<uint8_t> d_pool_info;
+    DeviceBuffer<uint32_t> d_wf_live;            // device counters of the bounce stage, two sets of four
+    DeviceBuffer<uint32_t> d_pool_list;          // live pools by class, 2 x tiles
+    DeviceBuffer<unsigned long long> d_wf_dbg;   // RWR_WF_STATS=1: pool classification counters, printed at destroy
     uint32_t wf_group = 16;         // samples per launch group; tunable: RWR_WF_GROUP (1..32)
     float wf_packet_fill = 0.25f;   // pools filled at least this much are traced as packets; tunable: RWR_WF_PACKET_FILL (> 1: never)
     uint32_t last_segments = 0;     // tiles of the last wavefront frame
+    uint32_t wf_parity = 0;         // which pair of live-pool counters the next launch group uses
     uint32_t last_spp = 0;
     bool last_had_bounce = false;
     // one decoded texture per scene part (texels decoded to linear f32 at upload, Rgba8UnormSrgb semantics)
@@ -402,6 +410,7 @@ int rebuild_tris(rwr_context *ctx)
         RWR_HIP_CHECK(hipMemcpy(ctx->d_bvh_leaf_faces.ptr, bvh.leaf_faces.data(), bvh.leaf_faces.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     ctx->bvh_n_nodes = (uint32_t)bvh.nodes.size();
     ctx->bvh_depth = bvh.max_depth;
+    ctx->bvh_leaf_extent = bvh.mean_leaf_extent;
     ctx->n_tris = total;
     ctx->tris_dirty = false;
     return RWR_OK;
@@ -456,6 +465,10 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     if (const char *e4 = std::getenv("RWR_ONE_PIXEL_PER_LANE")) ctx->force_one_pixel = std::atoi(e4) != 0;
     if (const char *e5 = std::getenv("RWR_AUTO_BVH_FACE_PX")) ctx->auto_bvh_face_px = (float)std::atof(e5);
     if (const char *e6 = std::getenv("RWR_WF_GROUP")) ctx->wf_group = std::min(kWfMaxGroup, std::max(1u, (uint32_t)std::strtoul(e6, nullptr, 10)));
+    if (const char *e9 = std::getenv("RWR_WF_STATS")) {
+        if (std::atoi(e9) && ctx->d_wf_dbg.ensure(4) == hipSuccess) (void)hipMemset(ctx->d_wf_dbg.ptr, 0, 32);
+    }
+    if (const char *e8 = std::getenv("RWR_WF_PACKET_EXTENT")) ctx->wf_packet_extent = (float)std::atof(e8);
     if (const char *e7 = std::getenv("RWR_WF_PACKET_FILL")) ctx->wf_packet_fill = (float)std::atof(e7);
     if (const char *e3 = std::getenv("RWR_BIN_MIN_FACES")) ctx->bin_min_faces = (uint32_t)std::strtoul(e3, nullptr, 10);
     *out_ctx = ctx;
@@ -467,10 +480,17 @@ void rwr_ctx_destroy(rwr_context *ctx)
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     (void)sync_all(ctx);
+    if (ctx->d_wf_dbg.ptr) {
+        unsigned long long h[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(h, ctx->d_wf_dbg.ptr, sizeof h, hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "rwr wavefront pools: packets %llu pools / %llu rays, per-lane %llu pools / %llu rays (leaf extent %g)\n",
+                     h[0], h[1], h[2], h[3], (double)ctx->bvh_leaf_extent);
+        ctx->d_wf_dbg.release();
+    }
     ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
     ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
-    ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wave_total.release(); for (auto &t : ctx->d_texs) t.release();
+    ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wave_total.release(); ctx->d_wf_fix.release(); ctx->d_pool_info.release(); ctx->d_wf_live.release(); ctx->d_pool_list.release(); for (auto &t : ctx->d_texs) t.release();
     ctx->d_face_mat.release(); ctx->d_materials.release();
     for (FrameSlot &sl : ctx->slots) {
         sl.release_buffers();
@@ -822,7 +842,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         RWR_HIP_CHECK(launch_primary_dormant(stream, fp, st, ctx->d_tris.ptr, ctx->d_shade.ptr, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront && ((rp.flags & RWR_FLAG_USE_BVH) || auto_bvh)) {
-        const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
+        const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u, 0.0f};
         RWR_HIP_CHECK(launch_primary_bvh(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh_p, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront) {
@@ -849,16 +869,25 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
             RWR_HIP_CHECK(ctx->d_q2.ensure(slots));
             RWR_HIP_CHECK(ctx->d_wf_sorted.ensure(slots));
             RWR_HIP_CHECK(ctx->d_wf_masks.ensure((size_t)n_tiles * group * 8u));
+            RWR_HIP_CHECK(ctx->d_wf_fix.ensure(3u * n));
+            RWR_HIP_CHECK(ctx->d_pool_info.ensure((size_t)n_tiles * wf_pool_info_bytes()));
+            RWR_HIP_CHECK(ctx->d_pool_list.ensure(2u * (size_t)n_tiles));
+            if (!ctx->d_wf_live.ptr) {
+                RWR_HIP_CHECK(ctx->d_wf_live.ensure(8));
+                RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wf_live.ptr, 0, 8 * sizeof(uint32_t), stream));
+            }
         }
-        const WfBuffers wf{ctx->d_accum.ptr, ctx->d_q0.ptr, ctx->d_q1.ptr, ctx->d_q2.ptr, ctx->d_wf_masks.ptr, ctx->d_wf_sorted.ptr,
-                           ctx->d_wave_total.ptr, group, tiles_x};
-        const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u};
-        for (uint32_t s0 = 0; s0 < rp.spp; s0 += group) {
+        const WfBuffers wf{ctx->d_accum.ptr, ctx->d_wf_fix.ptr, ctx->d_q0.ptr, ctx->d_q1.ptr, ctx->d_q2.ptr, ctx->d_wf_masks.ptr, ctx->d_wf_sorted.ptr,
+                           ctx->d_wave_total.ptr, group, tiles_x, ctx->d_wf_dbg.ptr};
+        const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u,
+                            ctx->wf_packet_extent * ctx->bvh_leaf_extent};
+        for (uint32_t s0 = 0, g = 0; s0 < rp.spp; s0 += group, g++) {
             const uint32_t cnt = std::min(group, rp.spp - s0);
             RWR_HIP_CHECK(launch_wf_primary(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0, tg, wf, s0, cnt));
             if (rp.max_bounces)
                 RWR_HIP_CHECK(launch_wf_bounce(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh, tex0, wf, n_tiles, cnt,
-                                               (uint32_t)std::fmax(1.0f, std::ceil(ctx->wf_packet_fill * (float)(cnt * kWfTilePixels)))));
+                                               (uint32_t)std::fmax(1.0f, std::ceil(ctx->wf_packet_fill * (float)(cnt * kWfTilePixels))),
+                                               ctx->d_pool_info.ptr, ctx->d_wf_live.ptr, ctx->d_pool_list.ptr, (ctx->wf_parity++) & 1u));
         }
         RWR_HIP_CHECK(launch_wf_resolve(stream, fp, tg, wf));
         ctx->last_spp = rp.spp;

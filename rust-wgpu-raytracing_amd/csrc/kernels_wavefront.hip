@@ -102,7 +102,13 @@ k_wf_resolve(const FrameParams p, const Targets tg, const WfBuffers wf)
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint32_t pixel = p.row_begin * p.width + i;
-    const float4 acc = wf.accum[pixel];
+    float4 acc = wf.accum[pixel];
+    if (p.bounces != 0u) {   // + the bounce stage's fixed-point sums (2^-26 units, kernels_wf_bounce.hip)
+        const size_t plane = (size_t)p.width * p.height;
+        acc.x += (float)wf.fix[pixel] * (1.0f / 67108864.0f);
+        acc.y += (float)wf.fix[plane + pixel] * (1.0f / 67108864.0f);
+        acc.z += (float)wf.fix[2u * plane + pixel] * (1.0f / 67108864.0f);
+    }
     const float fs = (float)p.spp;
     const float r = acc.x / fs, g = acc.y / fs, b = acc.z / fs, a = acc.w / fs;
     reinterpret_cast<uint32_t *>(tg.color)[pixel] = pack_rgba8(r, g, b, a);

@@ -1,8 +1,15 @@
 // Wavefront integrator, second stage: the bounce rays of one launch group (kernels_wf_primary.hip).
 //
-//   k_wf_bounce    one workgroup per TILE of the primary stage (64x8 pixels); its ray POOL is everything those
-//                  pixels emitted in the group's samples (up to 32 x 512 rays, origins within one small patch of
-//                  surface, directions all over the hemisphere).
+// The unit of work is a POOL: everything the 64x8 pixels of one tile of the primary stage emitted in the group's
+// samples (up to 32 x 512 rays: origins within one small patch of surface, directions all over the hemisphere).
+// Three kernels per launch group:
+//   k_wf_sort          (one workgroup per pool) steps 1 below + how the pool is traced;
+//   k_wf_trace_packet  well-filled compact pools: 128 rays per wave walk the BVH together (see there);
+//   k_wf_trace_lane    the other pools: one ray per lane, rwr_bvh.h.
+// The trace kernels are persistent (2048 workgroups pulling work items from a device counter); into how many work
+// items a pool is cut is decided ON THE DEVICE from the number of live pools the sort counted (pool_split): one
+// when the frame fills the chip by itself, up to 32 when only a few tiles see the mesh — otherwise four waves
+// would chew through thousands of rays while 250 CUs idle.
 //                  1. compaction + sort, in one: the ballots the primary stage published say which fixed queue
 //                     slots hold a ray; every ray's direction is binned (octant x 8x8 cells of the octahedral map,
 //                     Morton order inside an octant), a histogram / prefix sum / scatter through LDS atomics
@@ -21,6 +28,8 @@
 // Nothing here decides what the first hit shows; bounce rays are the oracle's rays bit for bit (first stage) and
 // their nearest hits are exact, so the stage's output differs from the oracle's only by float summation order
 // (tolerance 1e-4).
+#include <algorithm>
+
 #include "rwr_bvh.h"
 #include "rwr_device_p2.h"
 #include "rwr_primary.h"
@@ -42,25 +51,66 @@ RWR_DEV uint32_t direction_bin(f3 D)
     return oct * 64u + (mu | (mv << 1));
 }
 
-struct BouncePoolShared {
+// Per pool, written by k_wf_sort and read by the two trace kernels.
+struct PoolInfo {
+    uint32_t n_rays;         // 0: nothing to trace
+    uint32_t packets;        // 1: packet traversal, 0: per-lane traversal
+    uint32_t oct_begin[9];   // sorted position where each octant's rays begin; [8] = n_rays
+    uint32_t pad;
+};
+static_assert(sizeof(PoolInfo) == 48, "PoolInfo is 48 B");
+
+constexpr uint32_t kWfMaxSplit = 32;       // at most this many work items share one pool
+constexpr uint32_t kWfTargetItems = 4096;  // work items a trace launch should have (16 per CU)
+constexpr uint32_t kWfTraceGroups = 2048;  // workgroups of a trace launch (persistent: they pull work items)
+constexpr uint32_t kWfMinPacketPools = 128; // fewer packet pools than this in a launch group: the per-lane kernel takes them
+                                            // (a packet is one long chain of dependent scalar loads; a handful of them on an
+                                            // otherwise idle chip take longer than everything else in the frame)
+// device counters of one launch group (two sets, used alternately): pools of each class, work items handed out
+enum { kLivePackets = 0, kLiveLane = 1, kWorkPackets = 2, kWorkLane = 3, kCountersPerParity = 4 };
+
+// float -> uint32 key whose unsigned order is the float order
+RWR_DEV uint32_t float_key(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+RWR_DEV float key_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// Into how many work items a pool of a class with `live` pools in this launch group is cut: one when the frame
+// keeps the chip busy by itself, up to kWfMaxSplit when only a few tiles see anything (a small mesh on an empty
+// screen: otherwise four waves would walk through a pool of thousands of rays one after the other while 250 CUs idle).
+RWR_DEV uint32_t pool_split(uint32_t live)
+{
+    return live == 0u ? 1u : min(kWfMaxSplit, max(1u, (kWfTargetItems + live - 1u) / live));
+}
+
+struct SortShared {
     unsigned long long masks[kWfMaxGroup * 8u];
-    unsigned long long acc[kWfTilePixels * 3u];   // fixed-point sums of albedo * E(h1) per pixel of the tile
     uint32_t hist[kWfDirBins];
     uint32_t offs[kWfDirBins];
-    uint32_t oct_begin[9];   // sorted position where each octant's rays begin; [8] = ray count
+    uint32_t lo[3], hi[3];   // bounds of the ray origins of the group's first samples (order-preserving keys)
     uint32_t total;
-    uint32_t next_packet;
 };
 
-// Steps 0 and 1 for one pool: the published ballots -> live slot count; direction sort -> wf.sorted[pool] holds
-// the live slots octant by octant (octant o: sh.oct_begin[o] .. sh.oct_begin[o + 1]), fine bins in Morton order
-// inside.  Returns the number of rays (uniform over the workgroup).  Contains barriers.
-RWR_DEV uint32_t prepare_pool(BouncePoolShared &sh, const WfBuffers &wf, uint32_t tile, uint32_t sample_count, uint32_t min_rays,
-                              uint32_t max_rays)
+// Steps 0 and 1 for one pool: the published ballots -> live slot count; how it will be traced; direction sort ->
+// wf.sorted[pool] holds the live slots octant by octant, fine bins in Morton order inside; the pool is appended to
+// its class's list.  Queue reads are issued eight at a time per thread (the kernel is all memory latency).
+// A pool is traced as PACKETS when it is well filled (min_fill rays) and its rays start close together compared
+// with the geometry (origins within bvh.packet_extent): then the rays of one direction bin really travel
+// together.  A tile that spans many small faces (a distant instance) is not such a pool.
+__global__ void __launch_bounds__(256)
+k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list,
+          uint32_t n_tiles, uint32_t parity, uint32_t sample_count, uint32_t min_fill, float packet_extent)
 {
-    const uint32_t tid = threadIdx.x;
+    __shared__ SortShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    uint16_t *s_bins = reinterpret_cast<uint16_t *>(s_dyn);   // direction bin of every slot (0xffff: no ray); 2 B x sample_count x 512
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t n_masks = sample_count * 8u, n_slots = sample_count * kWfTilePixels;
+    if (tile == 0u && tid < (uint32_t)kCountersPerParity) counters[(parity ^ 1u) * kCountersPerParity + tid] = 0u;   // the next launch group's
     if (tid == 0u) sh.total = 0u;
+    if (tid < 3u) { sh.lo[tid] = 0xffffffffu; sh.hi[tid] = 0u; }
     __syncthreads();
     if (tid < n_masks) {
         const unsigned long long m = wf.masks[(size_t)tile * wf.group * 8u + tid];
@@ -68,16 +118,67 @@ RWR_DEV uint32_t prepare_pool(BouncePoolShared &sh, const WfBuffers &wf, uint32_
         if (m) atomicAdd(&sh.total, (uint32_t)__popcll(m));
     }
     for (uint32_t i = tid; i < kWfDirBins; i += 256u) sh.hist[i] = 0u;
-    for (uint32_t i = tid; i < kWfTilePixels * 3u; i += 256u) sh.acc[i] = 0ull;
     __syncthreads();
     const uint32_t n_rays = sh.total;
-    if (n_rays < min_rays || n_rays >= max_rays) return 0u;  // nothing here, or the other kernel's pool (uniform)
-
+    if (n_rays == 0u) {  // uniform
+        if (tid == 0u) info[tile].n_rays = 0u;
+        return;
+    }
     const size_t pool_base = (size_t)tile * wf.group * kWfTilePixels;
-    for (uint32_t e = tid; e < n_slots; e += 256u) {  // e = sample * 512 + wave * 128 + k * 64 + lane
-        if ((sh.masks[e >> 6] >> (e & 63u)) & 1ull) {
-            const float4 d = wf.q1[pool_base + e];
-            atomicAdd(&sh.hist[direction_bin(mk3(d.x, d.y, d.z))], 1u);
+    bool packets = n_rays >= min_fill;
+    if (packets) {   // uniform: how far apart do the rays start?  (the first two samples' slots)
+        float4 o[4];
+        bool live_slot[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t e = tid + 256u * (uint32_t)u;
+            live_slot[u] = e < n_slots && ((sh.masks[e >> 6] >> (e & 63u)) & 1ull);
+            o[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (live_slot[u]) o[u] = wf.q0[pool_base + e];
+        }
+        uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (live_slot[u]) {
+                const uint32_t k[3] = {float_key(o[u].x), float_key(o[u].y), float_key(o[u].z)};
+#pragma unroll
+                for (int c = 0; c < 3; c++) { lo[c] = min(lo[c], k[c]); hi[c] = max(hi[c], k[c]); }
+            }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                lo[c] = min(lo[c], (uint32_t)__shfl_xor((int)lo[c], d));
+                hi[c] = max(hi[c], (uint32_t)__shfl_xor((int)hi[c], d));
+            }
+        if ((tid & 63u) == 0u)
+            for (int c = 0; c < 3; c++) { atomicMin(&sh.lo[c], lo[c]); atomicMax(&sh.hi[c], hi[c]); }
+        __syncthreads();
+        float ext = 0.0f;
+        if (sh.hi[0] >= sh.lo[0])
+            ext = fmaxf(fmaxf(key_float(sh.hi[0]) - key_float(sh.lo[0]), key_float(sh.hi[1]) - key_float(sh.lo[1])),
+                        key_float(sh.hi[2]) - key_float(sh.lo[2]));
+        packets = ext <= packet_extent;   // a NaN extent: no packets
+    }
+    // histogram of the direction bins; e = sample * 512 + wave * 128 + k * 64 + lane
+    for (uint32_t e0 = tid; e0 < n_slots; e0 += 256u * 8u) {
+        float4 d[8];
+        bool live_slot[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t e = e0 + 256u * (uint32_t)u;
+            live_slot[u] = e < n_slots && ((sh.masks[e >> 6] >> (e & 63u)) & 1ull);
+            d[u] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+            if (live_slot[u]) d[u] = wf.q1[pool_base + e];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t e = e0 + 256u * (uint32_t)u;
+            if (e < n_slots) {
+                const uint32_t bin = live_slot[u] ? direction_bin(mk3(d[u].x, d[u].y, d[u].z)) : 0xffffu;
+                s_bins[e] = (uint16_t)bin;
+                if (live_slot[u]) atomicAdd(&sh.hist[bin], 1u);
+            }
         }
     }
     __syncthreads();
@@ -85,24 +186,38 @@ RWR_DEV uint32_t prepare_pool(BouncePoolShared &sh, const WfBuffers &wf, uint32_
         uint32_t sum = 0;
         for (uint32_t j = 0; j < b; j++) sum += sh.hist[j];
         sh.offs[b] = sum;
-        if ((b & 63u) == 0u) sh.oct_begin[b >> 6] = sum;
+        if ((b & 63u) == 0u) info[tile].oct_begin[b >> 6] = sum;
     }
-    if (tid == 0u) sh.oct_begin[8] = n_rays;
+    if (tid == 0u) {
+        info[tile].oct_begin[8] = n_rays;
+        info[tile].n_rays = n_rays;
+        info[tile].packets = packets ? 1u : 0u;
+        // append to the class's pool list (order of arrival: any order gives the same frame)
+        const uint32_t pos = atomicAdd(&counters[parity * kCountersPerParity + (packets ? kLivePackets : kLiveLane)], 1u);
+        pool_list[(packets ? 0u : n_tiles) + pos] = tile;
+        if (wf.dbg) {
+            atomicAdd(&wf.dbg[packets ? 0 : 2], 1ull);
+            atomicAdd(&wf.dbg[packets ? 1 : 3], (unsigned long long)n_rays);
+        }
+    }
     __syncthreads();
     uint16_t *__restrict__ sorted = wf.sorted + pool_base;
     for (uint32_t e = tid; e < n_slots; e += 256u) {
-        if ((sh.masks[e >> 6] >> (e & 63u)) & 1ull) {
-            const float4 d = wf.q1[pool_base + e];
-            sorted[atomicAdd(&sh.offs[direction_bin(mk3(d.x, d.y, d.z))], 1u)] = (uint16_t)e;
-        }
+        const uint32_t bin = s_bins[e];
+        if (bin != 0xffffu) sorted[atomicAdd(&sh.offs[bin], 1u)] = (uint16_t)e;
     }
-    __threadfence_block();
-    __syncthreads();
-    return n_rays;
 }
 
+// What a trace workgroup keeps in LDS: fixed-point sums of albedo * E(h1) per pixel of the tile.
+struct TraceShared {
+    unsigned long long acc[kWfTilePixels * 3u];
+    uint32_t oct_begin[9], pk_begin[9];   // packet kernel: where each octant's rays / packets begin
+    uint32_t next_packet;
+    uint32_t item;                        // the work item the workgroup pulled
+};
+
 // Adds one ray's contribution albedo(h0) * E(h1) to its pixel's fixed-point sums.  e: the ray's pool slot.
-RWR_DEV void add_contribution(BouncePoolShared &sh, uint32_t e, float cr, float cg, float cb)
+RWR_DEV void add_contribution(TraceShared &sh, uint32_t e, float cr, float cg, float cb)
 {
     const uint32_t r = e & (kWfTilePixels - 1u), w = r >> 7, k = (r >> 6) & 1u, l = r & 63u;
     const uint32_t lx = (w & 1u) * 32u + 2u * (l & 15u) + k, ly = (w >> 1) * 4u + (l >> 4);
@@ -113,81 +228,117 @@ RWR_DEV void add_contribution(BouncePoolShared &sh, uint32_t e, float cr, float 
     atomicAdd(dst + 2, (unsigned long long)(uint32_t)(cb * kWfFixedScale));
 }
 
-// Step 4: the pool's sums -> one read-modify-write of the RGBA32F accumulator per pixel.  Call after a barrier.
-RWR_DEV void flush_pool(BouncePoolShared &sh, const FrameParams &p, const WfBuffers &wf, uint32_t tile)
+// Step 4: the workgroup's sums -> the frame's fixed-point bounce planes (integer atomics: whichever workgroups
+// share the pool, in whatever order, the sums are the same bits).  Call after a barrier.
+RWR_DEV void flush_pool(TraceShared &sh, const FrameParams &p, const WfBuffers &wf, uint32_t tile)
 {
     const uint32_t tile_x0 = (tile % wf.tiles_x) * kWfTileW, tile_y0 = p.row_begin + (tile / wf.tiles_x) * kWfTileH;
+    const size_t plane = (size_t)p.width * p.height;
     for (uint32_t q = threadIdx.x; q < kWfTilePixels; q += 256u) {
         const uint32_t px = tile_x0 + (q & (kWfTileW - 1u)), py = tile_y0 + q / kWfTileW;
         const unsigned long long sr = sh.acc[q * 3u], sg = sh.acc[q * 3u + 1u], sb = sh.acc[q * 3u + 2u];
         if ((sr | sg | sb) != 0ull && px < p.width && py < p.row_end) {
-            const uint32_t pixel = py * p.width + px;
-            float4 acc = wf.accum[pixel];
-            acc.x += (float)sr * (1.0f / kWfFixedScale);
-            acc.y += (float)sg * (1.0f / kWfFixedScale);
-            acc.z += (float)sb * (1.0f / kWfFixedScale);
-            wf.accum[pixel] = acc;
+            const size_t pixel = (size_t)py * p.width + px;
+            if (sr) atomicAdd(&wf.fix[pixel], sr);
+            if (sg) atomicAdd(&wf.fix[plane + pixel], sg);
+            if (sb) atomicAdd(&wf.fix[2u * plane + pixel], sb);
         }
     }
 }
 
+// The trace kernels are PERSISTENT: kWfTraceGroups workgroups pull work items — (pool of the class, share of it)
+// — from a device counter until the class's live x split items are handed out.  Returns false when none are left.
+// Contains barriers; uniform over the workgroup.
+RWR_DEV bool next_item(TraceShared &sh, const PoolInfo *__restrict__ info, uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list,
+                       uint32_t parity, uint32_t n_tiles, uint32_t want_packets, uint32_t &tile, uint32_t &share, uint32_t &n_shares, PoolInfo &pi)
+{
+    const uint32_t live_p = counters[parity * kCountersPerParity + kLivePackets], live_l = counters[parity * kCountersPerParity + kLiveLane];
+    const bool demote = live_p < kWfMinPacketPools;
+    if (want_packets && demote) return false;
+    const uint32_t live = want_packets ? live_p : live_l + (demote ? live_p : 0u);
+    n_shares = pool_split(live);
+    __syncthreads();   // everybody is done with the previous item (sh.item, sh.acc)
+    if (threadIdx.x == 0u) sh.item = atomicAdd(&counters[parity * kCountersPerParity + (want_packets ? kWorkPackets : kWorkLane)], 1u);
+    __syncthreads();
+    // (values read back from LDS are uniform, but only we know that: readfirstlane keeps everything derived from
+    // them — and with it the traversal's node and face loads — on the scalar unit)
+    const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.item);
+    if (item >= live * n_shares) return false;
+    // item -> (share, pool): consecutive items are DIFFERENT pools, so that early items spread over the pools
+    share = item / live;
+    const uint32_t k = item % live;
+    const uint32_t list_pos = want_packets ? k : (k < live_l ? n_tiles + k : k - live_l);
+    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_list[list_pos]);
+    pi.n_rays = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[tile].n_rays);
+#pragma unroll
+    for (int o = 0; o < 9; o++) pi.oct_begin[o] = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[tile].oct_begin[o]);
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// Sparse pools (fewer than `max_rays` rays: silhouette tiles, small instances): one ray per lane, per-lane BVH
+// Pools that are sparse or spread out (silhouette tiles, distant instances): one ray per lane, per-lane BVH
 // traversal with the nodelets and the traversal stacks in LDS (rwr_bvh.h).
 template <bool NODES_IN_LDS>
 __global__ void __launch_bounds__(256)
-k_wf_bounce(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
-            const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf, uint32_t sample_count, uint32_t max_rays)
+k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
+                const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf, const PoolInfo *__restrict__ info,
+                uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list, uint32_t parity, uint32_t n_tiles)
 {
-    __shared__ BouncePoolShared sh;
+    __shared__ TraceShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
-    const uint32_t n_rays = prepare_pool(sh, wf, tile, sample_count, 1u, max_rays);
-    if (n_rays == 0u) return;
-
+    const uint32_t tid = threadIdx.x;
     // LDS carve of the dynamic part: [nodelets][traversal stack]
     BvhNode4 *s_nodes = reinterpret_cast<BvhNode4 *>(s_dyn);
     const uint32_t node_bytes = NODES_IN_LDS ? bvh.n_nodes * (uint32_t)sizeof(BvhNode4) : 0u;
     uint32_t *s_stack = reinterpret_cast<uint32_t *>(s_dyn + node_bytes);
-    if (NODES_IN_LDS) {
-        const float4 *src = reinterpret_cast<const float4 *>(bvh.nodes);
-        float4 *dst = reinterpret_cast<float4 *>(s_nodes);
-        for (uint32_t i = tid; i < bvh.n_nodes * 8u; i += 256u) dst[i] = src[i];
+    bool staged = false;
+    uint32_t tile, share, n_shares;
+    PoolInfo pi;
+    while (next_item(sh, info, counters, pool_list, parity, n_tiles, 0u, tile, share, n_shares, pi)) {
+        const uint32_t n_rays = pi.n_rays;
+        if (share * 256u >= n_rays) continue;   // uniform
+        if (NODES_IN_LDS && !staged) {
+            const float4 *src = reinterpret_cast<const float4 *>(bvh.nodes);
+            float4 *dst = reinterpret_cast<float4 *>(s_nodes);
+            for (uint32_t i = tid; i < bvh.n_nodes * 8u; i += 256u) dst[i] = src[i];
+            staged = true;
+        }
+        for (uint32_t i = tid; i < kWfTilePixels * 3u; i += 256u) sh.acc[i] = 0ull;
         __syncthreads();
-    }
-    const size_t pool_base = (size_t)tile * wf.group * kWfTilePixels;
-    const uint16_t *__restrict__ sorted = wf.sorted + pool_base;
-    for (uint32_t i = tid; i < n_rays; i += 256u) {
-        const uint32_t e = sorted[i];
-        const float4 a = wf.q0[pool_base + e], b = wf.q1[pool_base + e];
-        const float c = wf.q2[pool_base + e];
-        const f3 O = mk3(a.x, a.y, a.z), D = mk3(b.x, b.y, b.z);
-        const f3 thr = mk3(a.w, b.w, c);
+        const size_t pool_base = (size_t)tile * wf.group * kWfTilePixels;
+        const uint16_t *__restrict__ sorted = wf.sorted + pool_base;
+        for (uint32_t i = share * 256u + tid; i < n_rays; i += 256u * n_shares) {   // chunks of 256 sorted rays, dealt round-robin
+            const uint32_t e = sorted[i];
+            const float4 a = wf.q0[pool_base + e], b = wf.q1[pool_base + e];
+            const float c = wf.q2[pool_base + e];
+            const f3 O = mk3(a.x, a.y, a.z), D = mk3(b.x, b.y, b.z);
+            const f3 thr = mk3(a.w, b.w, c);
 
-        // nearest over spheres (in order), then the mesh; strict '<' keeps the earlier candidate on ties
-        bool have = false;
-        float best_t = 0.0f;
-        int32_t obj = -1;
-        for (uint32_t s = 0; s < p.n_spheres; s++) {
-            float t;
-            if (sphere_ray_intersect_t(ld3(p.spheres[s].center), p.spheres[s].radius, O, D, t)) {
-                if (!have || t < best_t) { have = true; best_t = t; obj = -2 - (int32_t)s; }
+            // nearest over spheres (in order), then the mesh; strict '<' keeps the earlier candidate on ties
+            bool have = false;
+            float best_t = 0.0f;
+            int32_t obj = -1;
+            for (uint32_t s = 0; s < p.n_spheres; s++) {
+                float t;
+                if (sphere_ray_intersect_t(ld3(p.spheres[s].center), p.spheres[s].radius, O, D, t)) {
+                    if (!have || t < best_t) { have = true; best_t = t; obj = -2 - (int32_t)s; }
+                }
+            }
+            MeshHit mh;
+            mh.have = false; mh.t = 0.0f; mh.u = 0.0f; mh.v = 0.0f; mh.ndotd = 0.0f; mh.idx = 0u;
+            if (p.n_tris) {
+                if (NODES_IN_LDS) bvh_nearest(s_nodes, bvh.leaf_faces, tris, p.n_tris, s_stack, O, D, mh);
+                else bvh_nearest(bvh.nodes, bvh.leaf_faces, tris, p.n_tris, s_stack, O, D, mh);
+                if (mh.have && (!have || mh.t < best_t)) { have = true; best_t = mh.t; obj = (int32_t)mh.idx; }
+            }
+            if (have) {
+                const f3 e1 = shade_winner(p, obj, best_t, mh.u, mh.v, mh.ndotd, shade, tex, O, D).colour;
+                add_contribution(sh, e, thr.x * e1.x, thr.y * e1.y, thr.z * e1.z);
             }
         }
-        MeshHit mh;
-        mh.have = false; mh.t = 0.0f; mh.u = 0.0f; mh.v = 0.0f; mh.ndotd = 0.0f; mh.idx = 0u;
-        if (p.n_tris) {
-            if (NODES_IN_LDS) bvh_nearest(s_nodes, bvh.leaf_faces, tris, p.n_tris, s_stack, O, D, mh);
-            else bvh_nearest(bvh.nodes, bvh.leaf_faces, tris, p.n_tris, s_stack, O, D, mh);
-            if (mh.have && (!have || mh.t < best_t)) { have = true; best_t = mh.t; obj = (int32_t)mh.idx; }
-        }
-        if (have) {
-            const f3 e1 = shade_winner(p, obj, best_t, mh.u, mh.v, mh.ndotd, shade, tex, O, D).colour;
-            add_contribution(sh, e, thr.x * e1.x, thr.y * e1.y, thr.z * e1.z);
-        }
+        __syncthreads();
+        flush_pool(sh, p, wf, tile);
     }
-    __syncthreads();
-    flush_pool(sh, p, wf, tile);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -200,6 +351,30 @@ k_wf_bounce(const FrameParams p, const TriRecord *__restrict__ tris, const Shade
 // packet can reach it; rays the box test excluded still run the exact test (it can only find true hits).
 // Same conservative slab test, same exact hit test and (t, face index) selection as the per-lane traversal, so the
 // winner of every ray is the brute-force winner.
+// Scene data the packet kernel reads at wave-uniform addresses, through the CONSTANT address space: the kernel is a
+// persistent loop with global atomics in it, and behind those the compiler would no longer dare to use scalar
+// loads for plain global pointers (it cannot see that nobody writes the scene) — node and face records would come
+// in through the vector memory pipe, 64 identical addresses per load.
+template <typename T> using const_ptr = const __attribute__((address_space(4))) T *;
+template <typename T> RWR_DEV const_ptr<T> to_const_space(const T *p) { return (const_ptr<T>)(p); }
+
+// The fields of a face record the hit test reads, loaded from the constant address space (the loads merge into four
+// s_load_dwordx8 when the index is wave-uniform).
+RWR_DEV TriRecord load_tri_record(const_ptr<TriRecord> rec)
+{
+    const const_ptr<float> f = (const_ptr<float>)rec;
+    TriRecord T;
+    T.p0[0] = f[0]; T.p0[1] = f[1]; T.p0[2] = f[2]; T.d = f[3];
+    T.p1[0] = f[4]; T.p1[1] = f[5]; T.p1[2] = f[6]; T.denom = f[7];
+    T.p2[0] = f[8]; T.p2[1] = f[9]; T.p2[2] = f[10]; T.pad0 = 0.0f;
+    T.N[0] = f[12]; T.N[1] = f[13]; T.N[2] = f[14]; T.pad1 = 0.0f;
+    T.e0[0] = f[16]; T.e0[1] = f[17]; T.e0[2] = f[18]; T.pad2 = 0.0f;
+    T.e1[0] = f[20]; T.e1[1] = f[21]; T.e1[2] = f[22]; T.pad3 = 0.0f;
+    T.e2[0] = f[24]; T.e2[1] = f[25]; T.e2[2] = f[26]; T.pad4 = 0.0f;
+    T.nhat[0] = T.nhat[1] = T.nhat[2] = 0.0f; T.pad5 = 0.0f;
+    return T;
+}
+
 struct PairRays {
     v3 O, D;             // the two rays of a lane
     f2 ix, iy, iz, ox, oy, oz;   // slab constants (rwr_bvh.h make_slab_ray)
@@ -264,34 +439,43 @@ RWR_DEV i2 sphere_pair_intersect_t(f3 center, float radius, v3 O, v3 D, f2 &t_ou
 
 template <int DUMMY>
 __global__ void __launch_bounds__(256)
-k_wf_bounce_packet(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
-                   const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf, uint32_t sample_count, uint32_t min_rays)
+k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
+                  const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf, const PoolInfo *__restrict__ info,
+                  uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list, uint32_t parity, uint32_t n_tiles)
 {
-    __shared__ BouncePoolShared sh;
-    const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t n_rays = prepare_pool(sh, wf, tile, sample_count, max(min_rays, 1u), 0xffffffffu);
-    if (n_rays == 0u) return;
-    if (tid == 0u) sh.next_packet = 0u;
-    __syncthreads();
+    __shared__ TraceShared sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const const_ptr<BvhNode4> nodes = to_const_space(bvh.nodes);
+    const const_ptr<uint32_t> leaf_faces = to_const_space(bvh.leaf_faces);
+    const const_ptr<TriRecord> tris_c = to_const_space(tris);
+    uint32_t tile, share, n_shares;
+    PoolInfo pi;
+    while (next_item(sh, info, counters, pool_list, parity, n_tiles, 1u, tile, share, n_shares, pi)) {
     // packets never straddle an octant: packet q of octant o covers sorted[oct_begin[o] + 128 q ...)
-    uint32_t pk_begin[9];
-    pk_begin[0] = 0u;
+    uint32_t n_packets = 0;
 #pragma unroll
-    for (int o = 0; o < 8; o++) pk_begin[o + 1] = pk_begin[o] + (sh.oct_begin[o + 1] - sh.oct_begin[o] + 127u) / 128u;
-    const uint32_t n_packets = pk_begin[8];
+    for (int o = 0; o < 8; o++) {
+        if (tid == 0u) { sh.oct_begin[o] = pi.oct_begin[o]; sh.pk_begin[o] = n_packets; }
+        n_packets += (pi.oct_begin[o + 1] - pi.oct_begin[o] + 127u) / 128u;
+    }
+    if (share >= n_packets) continue;   // uniform
+    if (tid == 0u) { sh.oct_begin[8] = pi.oct_begin[8]; sh.pk_begin[8] = n_packets; sh.next_packet = 0u; }
+    for (uint32_t i = tid; i < kWfTilePixels * 3u; i += 256u) sh.acc[i] = 0ull;
+    __syncthreads();
     const size_t pool_base = (size_t)tile * wf.group * kWfTilePixels;
     const uint16_t *__restrict__ sorted = wf.sorted + pool_base;
-    const BvhNode4 *__restrict__ nodes = bvh.nodes;
 
     for (;;) {
         uint32_t pk = 0;
         if (lane == 0u) pk = atomicAdd(&sh.next_packet, 1u);
-        pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk);
+        pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk) * n_shares + share;   // this workgroup's share of the packets
         if (pk >= n_packets) break;
         uint32_t oct = 0;
 #pragma unroll
-        for (int o = 1; o < 8; o++) oct += (pk >= pk_begin[o]) ? 1u : 0u;
-        const uint32_t first = sh.oct_begin[oct] + (pk - pk_begin[oct]) * 128u, last = sh.oct_begin[oct + 1];
+        for (int o = 1; o < 8; o++) oct += (pk >= sh.pk_begin[o]) ? 1u : 0u;
+        oct = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct);
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sh.oct_begin[oct] + (pk - sh.pk_begin[oct]) * 128u));
+        const uint32_t last = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.oct_begin[oct + 1]);
         // Gray-coded octant -> sign bits (kernels: direction_bin): sz = bit 2, sy = bit 1 ^ sz, sx = bit 0 ^ sy
         const uint32_t sz = oct >> 2, sy = ((oct >> 1) & 1u) ^ sz, sx = (oct & 1u) ^ sy;
 
@@ -322,16 +506,16 @@ k_wf_bounce_packet(const FrameParams p, const TriRecord *__restrict__ tris, cons
             uint32_t cur = 0;   // the root is always an inner node
             for (;;) {
                 if (!(cur & kBvhLeafBit)) {
-                    const BvhNode4 &nd = nodes[cur];   // wave-uniform index: scalar loads
-                    const float *nearx = sx ? nd.bmax_x : nd.bmin_x, *farx = sx ? nd.bmin_x : nd.bmax_x;
-                    const float *neary = sy ? nd.bmax_y : nd.bmin_y, *fary = sy ? nd.bmin_y : nd.bmax_y;
-                    const float *nearz = sz ? nd.bmax_z : nd.bmin_z, *farz = sz ? nd.bmin_z : nd.bmax_z;
+                    const const_ptr<BvhNode4> nd = nodes + cur;   // wave-uniform index: scalar loads
+                    const const_ptr<float> nearx = sx ? nd->bmax_x : nd->bmin_x, farx = sx ? nd->bmin_x : nd->bmax_x;
+                    const const_ptr<float> neary = sy ? nd->bmax_y : nd->bmin_y, fary = sy ? nd->bmin_y : nd->bmax_y;
+                    const const_ptr<float> nearz = sz ? nd->bmax_z : nd->bmin_z, farz = sz ? nd->bmin_z : nd->bmax_z;
                     // rays that are out of the running: invalid ones, and no distance beyond a ray's best hit matters
                     const f2 tb = f2{R.valid.x ? (best.have.x ? best.t.x : __builtin_inff()) : -1.0f,
                                      R.valid.y ? (best.have.y ? best.t.y : __builtin_inff()) : -1.0f};
                     // per child slot: entry-distance key (0xffffffff: nobody reaches it) and link — wave-uniform values
                     uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
-                    uint32_t c0 = nd.child[0], c1 = nd.child[1], c2 = nd.child[2], c3 = nd.child[3];
+                    uint32_t c0 = nd->child[0], c1 = nd->child[1], c2 = nd->child[2], c3 = nd->child[3];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const uint32_t child = i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3;
@@ -370,8 +554,11 @@ k_wf_bounce_packet(const FrameParams p, const TriRecord *__restrict__ tris, cons
                 } else {
                     const uint32_t lf = (cur & ~kBvhLeafBit) >> 3, count = (cur & 7u) + 1u;
                     for (uint32_t k = 0; k < count; k++) {
-                        const uint32_t idx = bvh.leaf_faces[lf + k];   // uniform: scalar load
-                        if (idx < p.n_tris) intersect_pair_any_order(tris[idx], idx, R, best);
+                        const uint32_t idx = leaf_faces[lf + k];   // uniform: scalar load
+                        if (idx < p.n_tris) {
+                            const TriRecord T = load_tri_record(tris_c + idx);   // into scalar registers
+                            intersect_pair_any_order(T, idx, R, best);
+                        }
                     }
                     if (sp == 0u) break;
                     sp--;
@@ -414,36 +601,39 @@ k_wf_bounce_packet(const FrameParams p, const TriRecord *__restrict__ tris, cons
     }
     __syncthreads();
     flush_pool(sh, p, wf, tile);
+    }   // next work item
 }
 
 hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                             const BvhDevice &bvh, const float4 *tex, const WfBuffers &wf, uint32_t n_tiles,
-                            uint32_t sample_count, uint32_t packet_min_rays)
+                            uint32_t sample_count, uint32_t packet_min_rays, void *pool_info, uint32_t *counters,
+                            uint32_t *pool_list, uint32_t parity)
 {
     if (n_tiles == 0 || sample_count == 0) return hipSuccess;
-    const dim3 grid(n_tiles);
-    // pools of at least packet_min_rays rays: packet traversal (its one stack is a VGPR of 64 entries)
-    const bool packets = bvh.stack_depth <= 64u && packet_min_rays <= sample_count * kWfTilePixels;
-    const uint32_t split = packets ? packet_min_rays : 0xffffffffu;
+    PoolInfo *info = static_cast<PoolInfo *>(pool_info);
+    // well-filled, compact pools: packet traversal (its one stack is a VGPR of 64 entries)
+    const bool packets = bvh.stack_depth <= 64u && packet_min_rays <= sample_count * kWfTilePixels && bvh.packet_extent > 0.0f;
+    hipLaunchKernelGGL(k_wf_sort, dim3(n_tiles), dim3(256), (size_t)sample_count * kWfTilePixels * sizeof(uint16_t), s, wf, info, counters, pool_list, n_tiles, parity, sample_count,
+                       packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);
+    const dim3 grid(std::min(kWfTraceGroups, n_tiles * kWfMaxSplit));
     if (packets)
-        hipLaunchKernelGGL((k_wf_bounce_packet<0>), grid, dim3(256), 0, s, fp, tris, shade, bvh, tex, wf, sample_count, split);
-    if (split > 1u) {
-        // the rest: per-lane traversal
-        const size_t fixed = (size_t)bvh.stack_depth * 256u * 4u;
-        const size_t node_bytes = (size_t)bvh.n_nodes * sizeof(BvhNode4);
-        // nodelets go to LDS when the workgroup then still fits a CU at least three times (160 KiB LDS, ~19 KiB static)
-        if (node_bytes + fixed <= 28u * 1024u)
-            hipLaunchKernelGGL((k_wf_bounce<true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, shade, bvh, tex, wf, sample_count, split);
-        else
-            hipLaunchKernelGGL((k_wf_bounce<false>), grid, dim3(256), fixed, s, fp, tris, shade, bvh, tex, wf, sample_count, split);
-    }
+        hipLaunchKernelGGL((k_wf_trace_packet<0>), grid, dim3(256), 0, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles);
+    const size_t fixed = (size_t)bvh.stack_depth * 256u * 4u;
+    const size_t node_bytes = (size_t)bvh.n_nodes * sizeof(BvhNode4);
+    // nodelets go to LDS when the workgroup then still fits a CU at least four times (160 KiB LDS, 12 KiB static)
+    if (node_bytes + fixed <= 28u * 1024u)
+        hipLaunchKernelGGL((k_wf_trace_lane<true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles);
+    else
+        hipLaunchKernelGGL((k_wf_trace_lane<false>), grid, dim3(256), fixed, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles);
     return hipGetLastError();
 }
+
+size_t wf_pool_info_bytes() { return sizeof(PoolInfo); }
 
 hipError_t preload_kernels_wf_bounce()
 {
     hipFuncAttributes attr;
-    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((&k_wf_bounce<true>)));
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((&k_wf_trace_packet<0>)));
 }
 
 }  // namespace rwr

@@ -340,6 +340,11 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
         }
         a0.x += ar.x; a0.y += ag.x; a0.z += ab.x; a0.w += aa.x;
         wf.accum[pix0] = a0;
+        if (sample_begin == 0u && p.bounces != 0u) {   // the frame's fixed-point bounce sums start at 0
+            const size_t plane = (size_t)p.width * p.height;
+            wf.fix[pix0] = 0ull; wf.fix[plane + pix0] = 0ull; wf.fix[2u * plane + pix0] = 0ull;
+            if (in1) { wf.fix[pix0 + 1u] = 0ull; wf.fix[plane + pix0 + 1u] = 0ull; wf.fix[2u * plane + pix0 + 1u] = 0ull; }
+        }
         if (in1) {
             a1.x += ar.y; a1.y += ag.y; a1.z += ab.y; a1.w += aa.y;
             wf.accum[pix0 + 1u] = a1;

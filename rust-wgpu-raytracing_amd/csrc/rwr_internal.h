@@ -179,7 +179,8 @@ constexpr uint32_t kWfTileW = 64, kWfTileH = 8, kWfTilePixels = kWfTileW * kWfTi
 constexpr uint32_t kWfMaxGroup = 32;          // samples per launch group (LDS of the bounce stage is sized for it)
 constexpr uint32_t kWfDirBins = 512;          // 8 octants x 8x8 cells of the octahedral map
 struct WfBuffers {
-    float4 *accum;                 // W*H RGBA32F running sums (rgb = radiance, a = 2 * primary hits)
+    float4 *accum;                 // W*H RGBA32F running sums of the first hits' E(h0) (a = 2 * primary hits)
+    unsigned long long *fix;       // 3 planes of W*H: fixed-point (2^-26) sums of albedo(h0) * E(h1), red, green, blue
     float4 *q0, *q1;
     float *q2;
     unsigned long long *masks;
@@ -187,6 +188,7 @@ struct WfBuffers {
     uint32_t *wave_total;          // per tile and wave: bounce rays emitted over all groups of the frame
     uint32_t group;                // samples per launch group this frame
     uint32_t tiles_x;
+    unsigned long long *dbg;       // optional (RWR_WF_STATS=1): {packet pools, their rays, per-lane pools, their rays}
 };
 struct BvhNode4;
 struct BvhDevice {
@@ -194,6 +196,7 @@ struct BvhDevice {
     const uint32_t *leaf_faces;
     uint32_t n_nodes;
     uint32_t stack_depth;  // 3 * tree depth + 2
+    float packet_extent;   // pools whose ray origins span less than this are traced as packets (kernels_wf_bounce.hip)
 };
 
 hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
@@ -204,7 +207,9 @@ hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriReco
                              const WfBuffers &wf, uint32_t sample_begin, uint32_t sample_count);
 hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                             const BvhDevice &bvh, const float4 *tex, const WfBuffers &wf,
-                            uint32_t n_tiles, uint32_t sample_count, uint32_t packet_min_rays);
+                            uint32_t n_tiles, uint32_t sample_count, uint32_t packet_min_rays, void *pool_info, uint32_t *counters,
+                            uint32_t *pool_list, uint32_t parity);
+size_t wf_pool_info_bytes();
 hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                               const BvhDevice &bvh, const float4 *tex, const Targets &tg);
 hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf);
