@@ -10,7 +10,9 @@ mesh pass, /root/reference/src/lib.rs:1024-1184) through the C ABI of
 include/rwr_hip.h.  Scene, camera and targets are resident in HBM before the
 timed region.  With N > 1 the frame is split into N contiguous row bands (one
 process per GPU) and every step ends with ONE RCCL gather of the finished bands
-to rank 0 (north_star) — total work is fixed, so "scaling" is "strong".
+to rank 0 (north_star), issued by the library itself (rwr_dist_gather_rgba8; torch.distributed
+only carries the communicator id and the barriers, over gloo) — total work is fixed, so
+"scaling" is "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     — dominant kernel against BOTH roofs: the binding one (VALU issue: the
@@ -62,13 +64,6 @@ CONFIGS = {
                  camera=dict(eye=(0, 0, 12), target=(0, 0, -1)),
                  label="suzanne_lowpoly.obj x16 instanced 3840x2160 64spp + 1 bounce (configs[4])"),
 }
-
-
-class _DevArray:
-    """Zero-copy view of device memory for torch.as_tensor (__cuda_array_interface__)."""
-
-    def __init__(self, ptr: int, nbytes: int):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
 def cpu_baseline(cfg, budget_s: float) -> dict:
@@ -142,16 +137,17 @@ def main() -> int:
     dist = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        import torch.distributed as dist  # backend "nccl" is RCCL on ROCm
+        # torch.distributed is the CONTROL plane only (gloo over TCP): it carries RCCL's unique id from rank 0 to
+        # the others, the barriers around the timed region and the max-over-ranks of the timings.  The frame's data
+        # path — the single gather of finished bands — is RCCL called by librwr_hip.so itself (rwr_dist_*).
+        import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    from rwr_amd.partition import band_rows, gather_bands_equal, gather_bands_ragged, make_gather_list
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     w, h = cfg["width"], cfg["height"]
-    r0, r1 = band_rows(rank, world, h)
+    r0, r1 = rwr.dist_band(rank, world, h)
     model = rwr.load_model_compute(cfg["scene"])
     cam_inv = rwr.camera_build_inv_uniform(rwr.make_camera(aspect=w / h, **cfg["camera"]))
     params = rwr.make_params(spp=cfg["spp"], max_bounces=cfg["bounces"])
@@ -163,41 +159,29 @@ def main() -> int:
     if cfg.get("instances"):
         ctx.set_instances(rwr.make_instance_grid(cfg["instances"], 3.0))   # lib.rs:400-421 grid, 3.0 apart
     ctx.resize(w, h)
-    # A dedicated (non-null) torch stream carries the kernels, the RCCL gather and the
-    # timing events, so HIP events bracket exactly the launches of the timed region.
-    stream = torch.cuda.Stream(device=local_rank)
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
     if use_dist:
-        ctx.set_stream(stream.cuda_stream)   # the RCCL gather must follow the render in stream order
+        uid = torch.zeros(rwr.DIST_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.tensor(list(rwr.dist_get_unique_id()), dtype=torch.uint8)
+        dist.broadcast(uid, src=0)
+        ctx.dist_init(rank, world, bytes(uid.tolist()))   # RCCL communicator of this rank's context
 
     # Frames in flight: like a swapchain, the context owns two sets of targets and alternates between
     # them, so one frame's kernel ramps up while the previous frame's last waves drain (at 1080p about
     # 40 % of a lone frame kernel is its first and last waves' latency chain).  With a
-    # gather the band tensor is tied to one target set, and wavefront frames share one accumulator: 1.
+    # gather the root has one receive buffer, and wavefront frames share one accumulator: 1.
     primary_only = cfg["spp"] == 1 and cfg["bounces"] == 0
     fif = args.frames_in_flight if args.frames_in_flight else (2 if (primary_only and not use_dist) else 1)
-    if use_dist and fif != 1:
-        print("bench.py: --frames-in-flight > 1 is not supported with the gather", file=sys.stderr)
-        return 2
     ctx.set_frames_in_flight(fif)
 
-    band = None
-    gather_list = None
-    if use_dist:
-        d_color, _ = ctx.device_targets()
-        band = torch.as_tensor(_DevArray(d_color + r0 * w * 4, (r1 - r0) * w * 4), device=f"cuda:{local_rank}")
-        if rank == 0:
-            frame = torch.empty(h * w * 4, dtype=torch.uint8, device=f"cuda:{local_rank}")
-            gather_list = make_gather_list(frame, world, w, h, 4)
-    gather = gather_bands_equal if h % world == 0 else gather_bands_ragged
-
     render = ctx.render_call(cam_inv, params, (r0, r1))
+
+    gather = ctx.dist_gather_call(0) if use_dist else None
 
     def step():
         render()
         if use_dist:
-            gather(dist, band, gather_list, rank, 0)   # the frame's single collective (RCCL over xGMI)
+            gather()   # the frame's single collective: every band to rank 0 (RCCL over xGMI), stream-ordered after the render
 
     def barrier():
         if use_dist:
@@ -205,7 +189,7 @@ def main() -> int:
 
     # Shader clock and VALU issue cost under load, for the VALU roof (about 15 ms of arithmetic on every CU).  It runs
     # here, before the warm-up steps, like the scene upload and the BVH build: setup, not a step.
-    clk = ctx.measure_valu_clock(8) if rank == 0 else None
+    clk = ctx.measure_valu_clock(8)
 
     for _ in range(args.warmup):
         step()
@@ -262,13 +246,13 @@ def main() -> int:
         for _ in range(n_ro):
             render()
         render_only_ms = ctx.timer_end() / n_ro
-        t = torch.tensor([elapsed, dev_ms, render_only_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed, dev_ms, render_only_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms, render_only_ms = float(t[0]), float(t[1]), float(t[2])
 
     # path segments actually traced: W*H*spp primary rays + the bounce rays the queue carried
     primary_rays, bounce_rays = ctx.last_render_stats()
-    seg = torch.tensor([primary_rays + bounce_rays], dtype=torch.float64, device=f"cuda:{local_rank}")
+    seg = torch.tensor([primary_rays + bounce_rays], dtype=torch.float64)
     if use_dist:
         dist.all_reduce(seg, op=dist.ReduceOp.SUM)
     rays_per_frame = float(seg[0])
@@ -278,8 +262,7 @@ def main() -> int:
     gathered_ok = None
     if use_dist and rank == 0:
         # the gathered frame must equal what a single GPU renders (checked once, outside the timed region)
-        torch.cuda.synchronize()
-        got = frame.cpu().numpy().reshape(h, w, 4)
+        got = ctx.dist_readback()                        # waits for the last gather
         ctx.render(cam_inv, params)                      # the whole frame on this rank alone
         gathered_ok = bool((got == ctx.readback()["color"]).all())
     out = None
@@ -359,6 +342,8 @@ def main() -> int:
             out["ms_per_frame_render_only"] = round(render_only_ms, 5)   # slowest rank's band, no gather (not timed above)
         if gathered_ok is not None:
             out["config"]["gathered_frame_ok"] = gathered_ok
+    if use_dist:
+        ctx.dist_destroy()
     ctx.close()
     if use_dist:
         dist.destroy_process_group()

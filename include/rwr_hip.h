@@ -162,7 +162,8 @@ RWR_API int rwr_ctx_device_info(rwr_context *ctx, char *name, size_t name_cap, i
  * buffers, each with its own HIP stream, and consecutive rwr_render calls take them in turn, the way a
  * swapchain hands out images (the reference takes each frame from wgpu's surface and presents it, lib.rs:1013,1227): the
  * next frame's kernels fill the GPU while the previous frame's last waves drain.  rwr_readback and
- * rwr_get_device_targets refer to the frame rendered last and wait for that frame only; a frame's
+ * rwr_get_device_targets refer to the frame rendered last (rwr_readback waits for that frame only,
+ * rwr_get_device_targets orders the context's stream after it); a frame's
  * targets stay valid until n further frames have been rendered.  rwr_synchronize, scene changes,
  * rwr_resize and rwr_ctx_set_stream wait for all frames in flight.  Slot 0 uses the context's stream
  * (rwr_ctx_set_stream), the others internal streams. */
@@ -243,10 +244,37 @@ RWR_API int rwr_readback(rwr_context *ctx, uint8_t *rgba8, float *depth,
                          float *rgba_f32, int32_t *obj_id, float *hit_t);
 
 /* Device addresses of the targets of the frame rendered last, for zero-copy consumers
- * (RCCL gather of finished bands, presentation).  They stay the same from frame to frame
- * with one frame in flight (the default) and alternate between the target sets otherwise;
+ * (presentation, interop).  Does not wait on the host: it orders the context's stream
+ * (rwr_ctx_get_stream) after that frame, so work the caller enqueues there next sees the finished
+ * targets; a consumer on another stream synchronises with rwr_synchronize.  The addresses stay the same from frame to
+ * frame with one frame in flight (the default) and alternate between the target sets otherwise;
  * valid until the next rwr_resize / rwr_ctx_set_frames_in_flight. */
 RWR_API int rwr_get_device_targets(rwr_context *ctx, void **d_rgba8, void **d_depth);
+
+/* ------------------------------------------------------- multi-GPU frames -- */
+/* The reference is single-device (one wgpu Adapter/Device, src/lib.rs:266-303, one surface, :1226); north_star asks
+ * for frames partitioned across the GPUs of a node with a single RCCL gather of the finished tiles.  Model: ONE
+ * PROCESS AND ONE CONTEXT PER GPU (rwr_ctx_create(device)), every rank holds the whole scene and renders its row
+ * band with rwr_render_rows (pixels and the RNG are keyed by global coordinates: bands assemble bit-identically),
+ * then every rank calls rwr_dist_gather_rgba8: its band goes to `root` over xGMI — RCCL point-to-point sends
+ * grouped into one operation, enqueued on the stream of the frame just rendered, bands landing in final image
+ * order in a buffer the root's context owns.  RCCL is loaded at run time by rwr_dist_get_unique_id / rwr_dist_init;
+ * hosts that never call these need no RCCL.
+ *   rank 0:  rwr_dist_get_unique_id(id)  -> the launcher hands `id` to every rank (any channel: a file, a socket,
+ *            torchrun's store) ->  all ranks: rwr_dist_init(ctx, rank, world, id).                                */
+#define RWR_DIST_ID_BYTES 128
+RWR_API int rwr_dist_get_unique_id(uint8_t id[RWR_DIST_ID_BYTES]);
+RWR_API int rwr_dist_init(rwr_context *ctx, int rank, int world, const uint8_t id[RWR_DIST_ID_BYTES]);
+/* The band partition every rank must use: rows [rank*H/world, (rank+1)*H/world). */
+RWR_API int rwr_dist_band(uint32_t rank, uint32_t world, uint32_t height, uint32_t *row_begin, uint32_t *row_end);
+/* Collective, asynchronous (stream-ordered after the frame rendered last). */
+RWR_API int rwr_dist_gather_rgba8(rwr_context *ctx, int root);
+/* Root only: device address of the assembled W*H*4 frame / copy to the host (waits for the gather). */
+RWR_API int rwr_dist_frame(rwr_context *ctx, void **d_rgba8);
+RWR_API int rwr_dist_readback(rwr_context *ctx, uint8_t *rgba8);
+/* Collective: returns when every rank's frames in flight have finished (an all-reduce of one word). */
+RWR_API int rwr_dist_barrier(rwr_context *ctx);
+RWR_API int rwr_dist_destroy(rwr_context *ctx);
 
 /* hipEvent timing on the stream(s) the kernels are launched on: rwr_timer_begin waits until nothing
  * is in flight and records; rwr_timer_end joins every frame in flight into the end event. */

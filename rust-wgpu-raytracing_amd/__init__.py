@@ -110,6 +110,9 @@ def lib() -> C.CDLL:
         "rwr_write_png_rgba8": [C.c_char_p, vp, u32, u32, i32, i32],
         "rwr_ctx_set_kernel_timing": [vp, u32], "rwr_kernel_timing_stats": [vp, vp, vp],
         "rwr_selftest_exact_math": [vp, u32, u32, vp], "rwr_ctx_set_frames_in_flight": [vp, u32],
+        "rwr_dist_get_unique_id": [vp], "rwr_dist_init": [vp, i32, i32, vp], "rwr_dist_band": [u32, u32, u32, vp, vp],
+        "rwr_dist_gather_rgba8": [vp, i32], "rwr_dist_frame": [vp, vp], "rwr_dist_readback": [vp, vp],
+        "rwr_dist_barrier": [vp], "rwr_dist_destroy": [vp],
         "rwr_measure_valu_clock": [vp, u32, vp], "rwr_clock_probe_start": [vp, u32], "rwr_clock_probe_read": [vp, vp],
     }
     for name, argtypes in sigs.items():
@@ -246,6 +249,23 @@ def load_model_parts(file_name: str, res_dir: str = RES_DIR) -> list:
     finally:
         L.rwr_model_free(h)
     return parts
+
+
+# ----------------------------------------------------------------- multi-GPU frames --
+DIST_ID_BYTES = 128
+
+
+def dist_get_unique_id() -> bytes:
+    """RCCL unique id (rank 0 creates it, the launcher hands it to every rank)."""
+    buf = (C.c_uint8 * DIST_ID_BYTES)()
+    _check(lib().rwr_dist_get_unique_id(buf))
+    return bytes(buf)
+
+
+def dist_band(rank: int, world: int, height: int) -> tuple[int, int]:
+    a, b = C.c_uint32(), C.c_uint32()
+    _check(lib().rwr_dist_band(rank, world, height, C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 # ------------------------------------------------------------------------ context --
@@ -400,6 +420,36 @@ class Context:
         out = (C.c_double * 4)()
         _check(lib().rwr_measure_valu_clock(self._h, waves_per_simd, out))
         return {"shader_mhz": out[0], "cycles_per_v_fma_f32": out[1], "cycles_per_v_pk_fma_f32": out[2], "shader_mhz_pk": out[3]}
+
+    def dist_init(self, rank: int, world: int, unique_id: bytes):
+        assert len(unique_id) == DIST_ID_BYTES
+        buf = (C.c_uint8 * DIST_ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib().rwr_dist_init(self._h, rank, world, buf))
+
+    def dist_gather(self, root: int = 0):
+        """The frame's single collective: every rank's finished RGBA8 band to `root` (RCCL, stream-ordered)."""
+        _check(lib().rwr_dist_gather_rgba8(self._h, root))
+
+    def dist_gather_call(self, root: int = 0):
+        fn, h, r = lib().rwr_dist_gather_rgba8, self._h, C.c_int(root)
+
+        def call():
+            rc = fn(h, r)
+            if rc:
+                _check(rc)
+
+        return call
+
+    def dist_readback(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        _check(lib().rwr_dist_readback(self._h, _p(out)))
+        return out
+
+    def dist_barrier(self):
+        _check(lib().rwr_dist_barrier(self._h))
+
+    def dist_destroy(self):
+        _check(lib().rwr_dist_destroy(self._h))
 
     def clock_probe_start(self, micros: int):
         _check(lib().rwr_clock_probe_start(self._h, micros))

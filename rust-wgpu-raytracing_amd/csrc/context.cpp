@@ -2,6 +2,9 @@
 // Replaces the wgpu plumbing of State (/root/reference/src/lib.rs:260-1231) with
 // one HIP stream and a handful of device buffers.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: the library is bound at run time (rwr_dist_init), never at link time
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -163,6 +166,13 @@ struct rwr_context {
     std::vector<hipEvent_t> timing_events;  // pairs
     uint32_t timing_pairs = 0;
     uint32_t wave_cull_min = 4;  // tunable: RWR_WAVE_CULL_MIN
+    // multi-GPU frame (rwr_dist_*): one process per GPU, one RCCL communicator per context
+    void *rccl_lib = nullptr;
+    ncclComm_t comm = nullptr;
+    int dist_rank = 0, dist_world = 0;
+    DeviceBuffer<uint8_t> d_gathered;    // root: the assembled RGBA8 frame
+    hipEvent_t gather_done = nullptr;    // orders consecutive gathers that run on different frame slots' streams
+    bool gathered_valid = false;
     // shader-clock probe (rwr_clock_probe_start / _read): one spinning wave on its own stream
     hipStream_t probe_stream = nullptr;
     DeviceBuffer<ulonglong2> d_probe;
@@ -500,6 +510,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
     for (hipEvent_t e : ctx->timing_events) (void)hipEventDestroy(e);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    (void)rwr_dist_destroy(ctx);
     if (ctx->probe_stream) { (void)hipStreamSynchronize(ctx->probe_stream); (void)hipStreamDestroy(ctx->probe_stream); }
     ctx->d_probe.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -733,9 +744,16 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     if (ctx->n_slots > 1u && (wavefront || ctx->last_spp != 0u)) RWR_HIP_CHECK(hipStreamSynchronize(ctx->slots[prev].stream));
     const hipStream_t stream = sl.stream;
     if (aux) {
+        // a band render leaves the rest of the planes untouched: they start zeroed, like the targets
+        const bool fresh = sl.d_color_f32.count < n * 4 || sl.d_obj_id.count < n || sl.d_hit_t.count < n;
         RWR_HIP_CHECK(sl.d_color_f32.ensure(n * 4));
         RWR_HIP_CHECK(sl.d_obj_id.ensure(n));
         RWR_HIP_CHECK(sl.d_hit_t.ensure(n));
+        if (fresh) {
+            RWR_HIP_CHECK(hipMemsetAsync(sl.d_color_f32.ptr, 0, n * 4 * sizeof(float), stream));
+            RWR_HIP_CHECK(hipMemsetAsync(sl.d_obj_id.ptr, 0, n * sizeof(int32_t), stream));
+            RWR_HIP_CHECK(hipMemsetAsync(sl.d_hit_t.ptr, 0, n * sizeof(float), stream));
+        }
     }
     const uint32_t total_tris = ctx->n_tris;
     RWR_HIP_CHECK(sl.d_ftris.ensure(total_tris));
@@ -939,6 +957,14 @@ int rwr_get_device_targets(rwr_context *ctx, void **d_rgba8, void **d_depth)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (ctx->screen.width == 0) return set_error(RWR_ERR_NOT_READY, "rwr_resize has not been called");
+    if (ctx->cur != 0u) {
+        // the frame rendered last ran on an internal stream: order the context's stream (rwr_ctx_get_stream) after it,
+        // so that whatever the caller enqueues there next sees the finished targets
+        DeviceGuard g(ctx->device);
+        FrameSlot &sl = ctx->slots[ctx->cur];
+        RWR_HIP_CHECK(hipEventRecord(sl.done, sl.stream));
+        RWR_HIP_CHECK(hipStreamWaitEvent(ctx->stream, sl.done, 0));
+    }
     if (d_rgba8) *d_rgba8 = ctx->slots[ctx->cur].d_color.ptr;
     if (d_depth) *d_depth = ctx->slots[ctx->cur].d_depth.ptr;
     return RWR_OK;
@@ -1118,6 +1144,173 @@ int rwr_last_render_stats(rwr_context *ctx, uint64_t *primary_rays, uint64_t *bo
     }
     if (primary_rays) *primary_rays = ctx->last_primary;
     if (bounce_rays) *bounce_rays = ctx->last_bounce;
+    return RWR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Multi-GPU frames: one process (and one context) per GPU, the frame cut into contiguous row bands, ONE gather of
+// the finished RGBA8 bands to the root per frame — RCCL point-to-point sends grouped into a single operation, over
+// xGMI.  RCCL is bound at run time: a single-GPU host never needs it.
+namespace {
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    void *lib = nullptr;
+};
+RcclApi g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.lib) return RWR_OK;
+    void *lib = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return set_error(RWR_ERR_UNSUPPORTED, "RCCL is not available: %s", dlerror());
+#define RWR_SYM(field, sym)                                                                           \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, sym));                         \
+    if (!g_rccl.field) return set_error(RWR_ERR_UNSUPPORTED, "RCCL symbol %s is missing", sym);
+    RWR_SYM(GetUniqueId, "ncclGetUniqueId") RWR_SYM(CommInitRank, "ncclCommInitRank") RWR_SYM(CommDestroy, "ncclCommDestroy")
+    RWR_SYM(GroupStart, "ncclGroupStart") RWR_SYM(GroupEnd, "ncclGroupEnd") RWR_SYM(Send, "ncclSend") RWR_SYM(Recv, "ncclRecv")
+    RWR_SYM(AllReduce, "ncclAllReduce") RWR_SYM(GetErrorString, "ncclGetErrorString")
+#undef RWR_SYM
+    g_rccl.lib = lib;
+    return RWR_OK;
+}
+
+#define RWR_NCCL_CHECK(expr)                                                                                     \
+    do {                                                                                                         \
+        ncclResult_t _r = (expr);                                                                                \
+        if (_r != ncclSuccess)                                                                                   \
+            return set_error(RWR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+}  // namespace
+
+int rwr_dist_band(uint32_t rank, uint32_t world, uint32_t height, uint32_t *row_begin, uint32_t *row_end)
+{
+    if (!row_begin || !row_end || world == 0u || rank >= world)
+        return set_error(RWR_ERR_INVALID_ARGUMENT, "rank %u outside world %u", rank, world);
+    *row_begin = (uint32_t)(((uint64_t)rank * height) / world);
+    *row_end = (uint32_t)((((uint64_t)rank + 1u) * height) / world);
+    return RWR_OK;
+}
+
+int rwr_dist_get_unique_id(uint8_t id[RWR_DIST_ID_BYTES])
+{
+    if (!id) return set_error(RWR_ERR_INVALID_ARGUMENT, "id is NULL");
+    static_assert(RWR_DIST_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "RWR_DIST_ID_BYTES is RCCL's unique id size");
+    const int rc = load_rccl();
+    if (rc != RWR_OK) return rc;
+    ncclUniqueId uid;
+    RWR_NCCL_CHECK(g_rccl.GetUniqueId(&uid));
+    std::memcpy(id, uid.internal, RWR_DIST_ID_BYTES);
+    return RWR_OK;
+}
+
+int rwr_dist_init(rwr_context *ctx, int rank, int world, const uint8_t id[RWR_DIST_ID_BYTES])
+{
+    if (!ctx || !id) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return set_error(RWR_ERR_INVALID_ARGUMENT, "rank %d outside world %d", rank, world);
+    if (ctx->comm) return set_error(RWR_ERR_INVALID_ARGUMENT, "the context already has a communicator");
+    const int rc = load_rccl();
+    if (rc != RWR_OK) return rc;
+    DeviceGuard g(ctx->device);
+    ncclUniqueId uid;
+    std::memcpy(uid.internal, id, RWR_DIST_ID_BYTES);
+    RWR_NCCL_CHECK(g_rccl.CommInitRank(&ctx->comm, world, uid, rank));
+    ctx->dist_rank = rank;
+    ctx->dist_world = world;
+    if (!ctx->gather_done) RWR_HIP_CHECK(hipEventCreateWithFlags(&ctx->gather_done, hipEventDisableTiming));
+    return RWR_OK;
+}
+
+int rwr_dist_gather_rgba8(rwr_context *ctx, int root)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (!ctx->comm) return set_error(RWR_ERR_NOT_READY, "rwr_dist_init has not been called");
+    if (root < 0 || root >= ctx->dist_world) return set_error(RWR_ERR_INVALID_ARGUMENT, "root %d outside world %d", root, ctx->dist_world);
+    if (ctx->screen.width == 0) return set_error(RWR_ERR_NOT_READY, "rwr_resize has not been called");
+    DeviceGuard g(ctx->device);
+    FrameSlot &sl = ctx->slots[ctx->cur];
+    const hipStream_t stream = sl.stream;   // the frame rendered last: the exchange follows it in stream order
+    const size_t row_bytes = (size_t)ctx->screen.width * 4u;
+    const bool is_root = ctx->dist_rank == root;
+    if (is_root) RWR_HIP_CHECK(ctx->d_gathered.ensure(row_bytes * ctx->screen.height));
+    if (ctx->n_slots > 1u) RWR_HIP_CHECK(hipStreamWaitEvent(stream, ctx->gather_done, 0));   // one receive buffer: gathers do not overlap
+    uint32_t r0 = 0, r1 = 0;
+    (void)rwr_dist_band((uint32_t)ctx->dist_rank, (uint32_t)ctx->dist_world, ctx->screen.height, &r0, &r1);
+    RWR_NCCL_CHECK(g_rccl.GroupStart());
+    if (r1 > r0)
+        RWR_NCCL_CHECK(g_rccl.Send(sl.d_color.ptr + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes, ncclUint8, root, ctx->comm, stream));
+    if (is_root)
+        for (int r = 0; r < ctx->dist_world; r++) {   // bands land in final image order
+            uint32_t a = 0, b = 0;
+            (void)rwr_dist_band((uint32_t)r, (uint32_t)ctx->dist_world, ctx->screen.height, &a, &b);
+            if (b > a)
+                RWR_NCCL_CHECK(g_rccl.Recv(ctx->d_gathered.ptr + (size_t)a * row_bytes, (size_t)(b - a) * row_bytes, ncclUint8, r, ctx->comm, stream));
+        }
+    RWR_NCCL_CHECK(g_rccl.GroupEnd());
+    RWR_HIP_CHECK(hipEventRecord(ctx->gather_done, stream));
+    ctx->gathered_valid = is_root;
+    return RWR_OK;
+}
+
+int rwr_dist_frame(rwr_context *ctx, void **d_rgba8)
+{
+    if (!ctx || !d_rgba8) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!ctx->gathered_valid) return set_error(RWR_ERR_NOT_READY, "no gathered frame on this rank (rwr_dist_gather_rgba8 on the root)");
+    *d_rgba8 = ctx->d_gathered.ptr;
+    return RWR_OK;
+}
+
+int rwr_dist_readback(rwr_context *ctx, uint8_t *rgba8)
+{
+    if (!ctx || !rgba8) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!ctx->gathered_valid) return set_error(RWR_ERR_NOT_READY, "no gathered frame on this rank (rwr_dist_gather_rgba8 on the root)");
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(hipEventSynchronize(ctx->gather_done));
+    RWR_HIP_CHECK(hipMemcpy(rgba8, ctx->d_gathered.ptr, (size_t)ctx->screen.width * ctx->screen.height * 4u, hipMemcpyDeviceToHost));
+    return RWR_OK;
+}
+
+int rwr_dist_barrier(rwr_context *ctx)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (!ctx->comm) return set_error(RWR_ERR_NOT_READY, "rwr_dist_init has not been called");
+    DeviceGuard g(ctx->device);
+    struct Scoped {
+        DeviceBuffer<uint32_t> b;
+        ~Scoped() { b.release(); }
+    } scoped;
+    RWR_HIP_CHECK(scoped.b.ensure(1));
+    RWR_HIP_CHECK(sync_all(ctx));
+    RWR_HIP_CHECK(hipMemsetAsync(scoped.b.ptr, 0, sizeof(uint32_t), ctx->stream));
+    RWR_NCCL_CHECK(g_rccl.AllReduce(scoped.b.ptr, scoped.b.ptr, 1, ncclUint32, ncclSum, ctx->comm, ctx->stream));
+    RWR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RWR_OK;
+}
+
+int rwr_dist_destroy(rwr_context *ctx)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (ctx->comm) {
+        DeviceGuard g(ctx->device);
+        (void)sync_all(ctx);
+        (void)g_rccl.CommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+    }
+    if (ctx->gather_done) { (void)hipEventDestroy(ctx->gather_done); ctx->gather_done = nullptr; }
+    ctx->d_gathered.release();
+    ctx->gathered_valid = false;
+    ctx->dist_world = 0;
     return RWR_OK;
 }
 

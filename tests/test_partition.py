@@ -22,6 +22,18 @@ def test_band_rows_tile_the_frame(rwr):
         band_rows(2, 2, 10)
 
 
+def test_library_band_partition_is_the_same(rwr):
+    """rwr_dist_band (what rwr_dist_gather_rgba8 uses for every rank's band) == partition.band_rows (what the gloo
+    rehearsal below assembles with)."""
+    from rwr_amd.partition import band_rows
+    for h in (1080, 2160, 54, 7, 1, 4321):
+        for n in (1, 2, 3, 4, 5, 8):
+            for r in range(n):
+                assert rwr.dist_band(r, n, h) == band_rows(r, n, h)
+    with pytest.raises(rwr.RwrError):
+        rwr.dist_band(2, 2, 10)
+
+
 def _worker(rank, world, port, height_cut, result_path):
     import sys
     import torch
