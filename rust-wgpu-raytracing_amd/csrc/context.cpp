@@ -118,6 +118,7 @@ struct rwr_context {
     uint32_t bvh_n_nodes = 0, bvh_depth = 0;
     float bvh_leaf_extent = 0.0f;
     float wf_packet_extent = 0.5f;   // x mean leaf extent; tunable: RWR_WF_PACKET_EXTENT
+    uint32_t wf_min_packet_pools = 128;   // tunable: RWR_WF_MIN_PACKET_POOLS
     float aabb_lo[3] = {0, 0, 0}, aabb_hi[3] = {0, 0, 0};   // of the (flattened) world-space faces
     float auto_bvh_face_px = 150.0f;   // tunable: RWR_AUTO_BVH_FACE_PX (0 = never pick the BVH kernel by itself)
     // wavefront integrator state
@@ -478,6 +479,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     if (const char *e9 = std::getenv("RWR_WF_STATS")) {
         if (std::atoi(e9) && ctx->d_wf_dbg.ensure(4) == hipSuccess) (void)hipMemset(ctx->d_wf_dbg.ptr, 0, 32);
     }
+    if (const char *e10 = std::getenv("RWR_WF_MIN_PACKET_POOLS")) ctx->wf_min_packet_pools = (uint32_t)std::strtoul(e10, nullptr, 10);
     if (const char *e8 = std::getenv("RWR_WF_PACKET_EXTENT")) ctx->wf_packet_extent = (float)std::atof(e8);
     if (const char *e7 = std::getenv("RWR_WF_PACKET_FILL")) ctx->wf_packet_fill = (float)std::atof(e7);
     if (const char *e3 = std::getenv("RWR_BIN_MIN_FACES")) ctx->bin_min_faces = (uint32_t)std::strtoul(e3, nullptr, 10);
@@ -860,7 +862,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         RWR_HIP_CHECK(launch_primary_dormant(stream, fp, st, ctx->d_tris.ptr, ctx->d_shade.ptr, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront && ((rp.flags & RWR_FLAG_USE_BVH) || auto_bvh)) {
-        const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u, 0.0f};
+        const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u, 0.0f, 0u};
         RWR_HIP_CHECK(launch_primary_bvh(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh_p, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront) {
@@ -898,7 +900,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         const WfBuffers wf{ctx->d_accum.ptr, ctx->d_wf_fix.ptr, ctx->d_q0.ptr, ctx->d_q1.ptr, ctx->d_q2.ptr, ctx->d_wf_masks.ptr, ctx->d_wf_sorted.ptr,
                            ctx->d_wave_total.ptr, group, tiles_x, ctx->d_wf_dbg.ptr};
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u,
-                            ctx->wf_packet_extent * ctx->bvh_leaf_extent};
+                            ctx->wf_packet_extent * ctx->bvh_leaf_extent, ctx->wf_min_packet_pools};
         for (uint32_t s0 = 0, g = 0; s0 < rp.spp; s0 += group, g++) {
             const uint32_t cnt = std::min(group, rp.spp - s0);
             RWR_HIP_CHECK(launch_wf_primary(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0, tg, wf, s0, cnt));

@@ -63,9 +63,9 @@ static_assert(sizeof(PoolInfo) == 48, "PoolInfo is 48 B");
 constexpr uint32_t kWfMaxSplit = 32;       // at most this many work items share one pool
 constexpr uint32_t kWfTargetItems = 4096;  // work items a trace launch should have (16 per CU)
 constexpr uint32_t kWfTraceGroups = 2048;  // workgroups of a trace launch (persistent: they pull work items)
-constexpr uint32_t kWfMinPacketPools = 128; // fewer packet pools than this in a launch group: the per-lane kernel takes them
-                                            // (a packet is one long chain of dependent scalar loads; a handful of them on an
-                                            // otherwise idle chip take longer than everything else in the frame)
+// Fewer packet pools than `min_packet_pools` (default 128, BvhDevice) in a launch group: the per-lane kernel takes them
+// (a packet is one long chain of dependent scalar loads; a handful of them on an otherwise idle chip take longer
+// than everything else in the frame).
 // device counters of one launch group (two sets, used alternately): pools of each class, work items handed out
 enum { kLivePackets = 0, kLiveLane = 1, kWorkPackets = 2, kWorkLane = 3, kCountersPerParity = 4 };
 
@@ -250,10 +250,11 @@ RWR_DEV void flush_pool(TraceShared &sh, const FrameParams &p, const WfBuffers &
 // — from a device counter until the class's live x split items are handed out.  Returns false when none are left.
 // Contains barriers; uniform over the workgroup.
 RWR_DEV bool next_item(TraceShared &sh, const PoolInfo *__restrict__ info, uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list,
-                       uint32_t parity, uint32_t n_tiles, uint32_t want_packets, uint32_t &tile, uint32_t &share, uint32_t &n_shares, PoolInfo &pi)
+                       uint32_t parity, uint32_t n_tiles, uint32_t want_packets, uint32_t min_packet_pools, uint32_t &tile, uint32_t &share,
+                       uint32_t &n_shares, PoolInfo &pi)
 {
     const uint32_t live_p = counters[parity * kCountersPerParity + kLivePackets], live_l = counters[parity * kCountersPerParity + kLiveLane];
-    const bool demote = live_p < kWfMinPacketPools;
+    const bool demote = live_p < min_packet_pools;
     if (want_packets && demote) return false;
     const uint32_t live = want_packets ? live_p : live_l + (demote ? live_p : 0u);
     n_shares = pool_split(live);
@@ -294,7 +295,7 @@ k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const S
     bool staged = false;
     uint32_t tile, share, n_shares;
     PoolInfo pi;
-    while (next_item(sh, info, counters, pool_list, parity, n_tiles, 0u, tile, share, n_shares, pi)) {
+    while (next_item(sh, info, counters, pool_list, parity, n_tiles, 0u, bvh.min_packet_pools, tile, share, n_shares, pi)) {
         const uint32_t n_rays = pi.n_rays;
         if (share * 256u >= n_rays) continue;   // uniform
         if (NODES_IN_LDS && !staged) {
@@ -450,7 +451,7 @@ k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const
     const const_ptr<TriRecord> tris_c = to_const_space(tris);
     uint32_t tile, share, n_shares;
     PoolInfo pi;
-    while (next_item(sh, info, counters, pool_list, parity, n_tiles, 1u, tile, share, n_shares, pi)) {
+    while (next_item(sh, info, counters, pool_list, parity, n_tiles, 1u, bvh.min_packet_pools, tile, share, n_shares, pi)) {
     // packets never straddle an octant: packet q of octant o covers sorted[oct_begin[o] + 128 q ...)
     uint32_t n_packets = 0;
 #pragma unroll

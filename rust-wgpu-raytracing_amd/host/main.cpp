@@ -3,12 +3,14 @@
 // input* -> update -> render, with key events taken from a script instead of a window.
 //
 //   rwr_render --res DIR [--scene suzanne_lowpoly.obj] [--size 600x600] [--keys "S*15,D*4"]
-//              [--frames N] [--spp N] [--bounces B] [--out frame.png] [--time]
+//              [--frames N] [--resize WxH@FRAME]... [--spp N] [--bounces B] [--out frame.png] [--time]
 //
 // --keys: comma separated KEY*COUNT; each entry holds KEY down for COUNT frames
 // (KEY in W A S D Up Down Left Right Space LShift, or '-' for no key).  After the script,
 // --frames more frames are rendered with no key held.  The window default is 600x600
-// (lib.rs:1248-1251).
+// (lib.rs:1248-1251).  --resize WxH@FRAME (repeatable): a WindowEvent::Resized delivered before frame FRAME
+// (0-based, counted over the whole run) -> State::resize (lib.rs:772-989, 1323-1330), including its quirk: the
+// camera's aspect is recomputed from the size BEFORE the resize.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +42,8 @@ int main(int argc, char **argv)
     std::string res, scene = "suzanne_lowpoly.obj", out, keys;
     uint32_t w = 600, h = 600, frames = 1, spp = 1, bounces = 0;
     bool timing = false;
+    struct Resize { uint64_t frame; uint32_t w, h; };
+    std::vector<Resize> resizes;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char * {
@@ -54,11 +58,18 @@ int main(int argc, char **argv)
         else if (a == "--spp") spp = (uint32_t)std::atoi(next());
         else if (a == "--bounces") bounces = (uint32_t)std::atoi(next());
         else if (a == "--time") timing = true;
+        else if (a == "--resize") {
+            Resize r{0, 0, 0};
+            unsigned long long f = 0;
+            if (std::sscanf(next(), "%ux%u@%llu", &r.w, &r.h, &f) != 3) { std::fprintf(stderr, "--resize WxH@FRAME\n"); return 2; }
+            r.frame = f;
+            resizes.push_back(r);
+        }
         else if (a == "--size") {
             if (std::sscanf(next(), "%ux%u", &w, &h) != 2) { std::fprintf(stderr, "--size WxH\n"); return 2; }
         } else if (a == "--help" || a == "-h") {
             std::printf("usage: rwr_render --res DIR [--scene F.obj] [--size WxH] [--keys \"S*15,D*4\"] [--frames N] "
-                        "[--spp N] [--bounces B] [--out frame.png] [--time]\n");
+                        "[--resize WxH@FRAME]... [--spp N] [--bounces B] [--out frame.png] [--time]\n");
             return 0;
         } else {
             std::fprintf(stderr, "unknown argument %s\n", a.c_str());
@@ -87,7 +98,9 @@ int main(int argc, char **argv)
         const rwr_render_params params{spp, bounces, 0u, 0u};
         uint64_t rendered = 0;
         const auto t0 = std::chrono::steady_clock::now();
-        auto frame = [&]() {  // RedrawRequested: update() then render() (lib.rs:1335-1337)
+        auto frame = [&]() {  // [Resized: resize()] then RedrawRequested: update() then render() (lib.rs:1323-1337)
+            for (const Resize &r : resizes)
+                if (r.frame == rendered) state.resize(r.w, r.h);
             state.update();
             state.render(&params);
             rendered++;
@@ -101,13 +114,14 @@ int main(int argc, char **argv)
         check(rwr_synchronize(state.context()));
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const Camera &c = state.camera();
-        std::printf("frames %llu  eye (%.6f, %.6f, %.6f)  target (%.6f, %.6f, %.6f)\n", (unsigned long long)rendered, c.eye.x, c.eye.y,
-                    c.eye.z, c.target.x, c.target.y, c.target.z);
+        std::printf("frames %llu  eye (%.6f, %.6f, %.6f)  target (%.6f, %.6f, %.6f)  size %ux%u  aspect %.9g\n", (unsigned long long)rendered,
+                    c.eye.x, c.eye.y, c.eye.z, c.target.x, c.target.y, c.target.z, state.size().width, state.size().height, (double)c.aspect);
         if (timing) std::printf("%.3f ms/frame over %llu frames (update + render, host wall clock)\n", sec * 1e3 / (double)rendered,
                                 (unsigned long long)rendered);
         if (!out.empty()) {
             state.present(out);
-            std::printf("wrote %s (%ux%u, row 0 of the framebuffer at the bottom, sRGB encoded)\n", out.c_str(), w, h);
+            std::printf("wrote %s (%ux%u, row 0 of the framebuffer at the bottom, sRGB encoded)\n", out.c_str(), state.size().width,
+                        state.size().height);
         }
     } catch (const RwrFailure &e) {
         std::fprintf(stderr, "rwr_render: error %d: %s\n", e.code, e.what());

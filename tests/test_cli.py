@@ -64,3 +64,44 @@ def test_cli_path_mode_and_cube(rwr, tmp_path):
     assert img.shape == (96, 96, 4) and (img[..., 3] == 255).any() and "ms/frame" in r.stdout
     r = subprocess.run([exe, "--res", rwr.RES_DIR, "--scene", "missing.obj"], capture_output=True, text=True)
     assert r.returncode == 1 and "error -4" in r.stderr                                   # RWR_ERR_IO, not a panic
+
+
+@pytest.mark.gpu
+def test_cli_resize_keeps_the_old_aspect(rwr, orc, suzanne, tmp_path):
+    """SURVEY §8(f) rank 1, the resize path: State::resize recomputes camera.aspect from the size BEFORE the resize
+    (/root/reference/src/lib.rs:772-777: line 774 runs before 776-777), re-creates the targets at the new size and
+    rewrites the screen uniform (:966-973).  After WxH -> W'xH' the frame is W'xH' pixels seen with aspect W/H; after a
+    second resize the aspect is W'/H'."""
+    exe = _exe(rwr)
+
+    def run(resizes, frames):
+        out = str(tmp_path / "resized.png")
+        cmd = [exe, "--res", rwr.RES_DIR, "--size", "160x120", "--keys", "S*15", "--frames", str(frames), "--out", out]
+        for r in resizes:
+            cmd += ["--resize", r]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        m = re.search(r"size (\d+)x(\d+)\s+aspect ([-\d.e]+)", r.stdout)
+        return int(m.group(1)), int(m.group(2)), float(m.group(3)), rwr.decode_image_rgba8(open(out, "rb").read()).astype(int)[::-1]
+
+    def want(w, h, aspect):
+        cam = orc.make_camera(aspect=aspect)
+        for _ in range(15):
+            cam = orc.controller_update(cam, orc.KEY_BACKWARD)
+        ref = orc.render_frame(orc.camera_build_inv_uniform(cam), orc.make_screen(w, h), orc.make_spheres(), suzanne)
+        lin = ref["color"].astype(float) / 255
+        enc = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(lin, 1 / 2.4) - 0.055)
+        enc[..., 3] = lin[..., 3]
+        return np.rint(enc * 255)
+
+    for resizes, frames, (ew, eh, easp) in (
+            (["200x100@16"], 3, (200, 100, np.float32(160) / np.float32(120))),                 # one resize: old aspect 4:3
+            (["200x100@16", "96x128@17"], 4, (96, 128, np.float32(200) / np.float32(100))),    # second resize: aspect 2:1
+    ):
+        w, h, aspect, got = run(resizes, frames)
+        assert (w, h) == (ew, eh) and abs(aspect - float(easp)) < 1e-6
+        assert got.shape == (eh, ew, 4)
+        d = np.abs(got - want(ew, eh, float(easp)))
+        assert d.max() <= 3 and (d > 0).mean() < 0.01
+        # and NOT the frame a "correct" resize would give (aspect from the new size) — the quirk is visible
+        assert np.abs(got - want(ew, eh, ew / eh)).max() > 3
