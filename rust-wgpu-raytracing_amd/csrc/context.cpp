@@ -83,13 +83,15 @@ struct FrameSlot {
     DeviceBuffer<FrameTri> d_ftris;
     DeviceBuffer<float> d_tnum;                  // per frame: plane-distance numerator per face
     DeviceBuffer<float4> d_ray_colp, d_ray_row;  // per frame: ray tables (FrameParams::ray_colp / ray_row)
-    DeviceBuffer<uint32_t> d_bin_lists, d_bin_counts;   // per-frame screen bins (large scenes)
+    DeviceBuffer<uint32_t> d_bin_lists, d_bin_counts, d_bin_offsets, d_bin_total;   // per-frame screen bins (large scenes)
+    uint32_t *h_bin_total = nullptr;   // pinned: entries the last binned frame of this slot needed (read a frame late, never waited for)
     bool aux_valid = false;
     void release_buffers()
     {
         d_color.release(); d_depth.release(); d_color_f32.release(); d_obj_id.release(); d_hit_t.release();
         d_ftris.release(); d_tnum.release(); d_ray_colp.release(); d_ray_row.release();
-        d_bin_lists.release(); d_bin_counts.release();
+        d_bin_lists.release(); d_bin_counts.release(); d_bin_offsets.release(); d_bin_total.release();
+        if (h_bin_total) { (void)hipHostFree(h_bin_total); h_bin_total = nullptr; }
     }
 };
 constexpr uint32_t kMaxFramesInFlight = 3;
@@ -111,6 +113,7 @@ struct rwr_context {
     DeviceBuffer<ShadeRec> d_shade;
     DeviceBuffer<CullRec> d_cull;
     uint32_t bin_min_faces = 256;                       // tunable: RWR_BIN_MIN_FACES
+    uint32_t bin_min_capacity = 65536;                  // tunable: RWR_BIN_CAPACITY (entries the bin lists start with)
     bool force_one_pixel = false;                       // debug: RWR_ONE_PIXEL_PER_LANE=1
     // BVH over the (flattened) world-space faces, for bounce rays
     DeviceBuffer<BvhNode4> d_bvh_nodes;
@@ -482,6 +485,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     if (const char *e10 = std::getenv("RWR_WF_MIN_PACKET_POOLS")) ctx->wf_min_packet_pools = (uint32_t)std::strtoul(e10, nullptr, 10);
     if (const char *e8 = std::getenv("RWR_WF_PACKET_EXTENT")) ctx->wf_packet_extent = (float)std::atof(e8);
     if (const char *e7 = std::getenv("RWR_WF_PACKET_FILL")) ctx->wf_packet_fill = (float)std::atof(e7);
+    if (const char *e11 = std::getenv("RWR_BIN_CAPACITY")) ctx->bin_min_capacity = (uint32_t)std::strtoul(e11, nullptr, 10);
     if (const char *e3 = std::getenv("RWR_BIN_MIN_FACES")) ctx->bin_min_faces = (uint32_t)std::strtoul(e3, nullptr, 10);
     *out_ctx = ctx;
     return RWR_OK;
@@ -825,15 +829,29 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     }
     if (ctx->n_tris && !(rp.flags & RWR_FLAG_NO_CULL)) {
         const uint32_t bins_x = (ctx->screen.width + kBinW - 1) / kBinW, bins_y = (row_end - row_begin + kBinH - 1) / kBinH;
-        // bin lists are worst-case sized (every face in every bin); beyond 2 GiB fall back to the un-binned walk
-        const bool bins_fit = (uint64_t)bins_x * bins_y * ctx->n_tris * sizeof(uint32_t) <= (2ull << 30);
-        if (ctx->n_tris > ctx->bin_min_faces && bins_fit) {
-            // more faces than one 256-wide batch: bin them per 64x32-pixel screen region, once per frame
-            RWR_HIP_CHECK(sl.d_bin_lists.ensure((size_t)bins_x * bins_y * ctx->n_tris));
-            RWR_HIP_CHECK(sl.d_bin_counts.ensure((size_t)bins_x * bins_y));
-            RWR_HIP_CHECK(launch_bin_faces(stream, sl.d_ftris.ptr, ctx->n_tris, row_begin, sl.d_bin_lists.ptr,
-                                           sl.d_bin_counts.ptr, bins_x, bins_y, ctx->n_tris));
-            fp.bins = BinGrid{sl.d_bin_lists.ptr, sl.d_bin_counts.ptr, bins_x, bins_y, ctx->n_tris, 1u};
+        if (ctx->n_tris > ctx->bin_min_faces) {
+            // more faces than one 256-wide batch: bin them per 64x32-pixel screen region, once per frame.  The lists
+            // are sized by a count pass on the device; the buffer keeps what the previous frames needed (read back a
+            // frame late through pinned memory, never waited for) with headroom, and a frame whose lists do not fit
+            // walks the whole scene instead — the same pixels — while the buffer grows for the next one.
+            const size_t n_bins = (size_t)bins_x * bins_y;
+            if (!sl.h_bin_total) {
+                RWR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&sl.h_bin_total), sizeof(uint32_t), hipHostMallocDefault));
+                *sl.h_bin_total = 0u;
+            }
+            const uint64_t needed = *sl.h_bin_total;
+            uint64_t capacity = std::max<uint64_t>(sl.d_bin_lists.count, std::max<uint64_t>(ctx->bin_min_capacity, ctx->bin_min_capacity >= 65536u ? 8ull * ctx->n_tris : 0ull));
+            if (needed > capacity || needed + needed / 4u > capacity) capacity = std::max<uint64_t>(capacity, needed + needed / 2u);
+            capacity = std::min<uint64_t>(capacity, 0xfffffff0ull);
+            if (capacity > sl.d_bin_lists.count) RWR_HIP_CHECK(hipStreamSynchronize(stream));   // the old buffer may still be read
+            RWR_HIP_CHECK(sl.d_bin_lists.ensure((size_t)capacity));
+            RWR_HIP_CHECK(sl.d_bin_counts.ensure(n_bins));
+            RWR_HIP_CHECK(sl.d_bin_offsets.ensure(n_bins));
+            RWR_HIP_CHECK(sl.d_bin_total.ensure(1));
+            RWR_HIP_CHECK(launch_bin_faces(stream, sl.d_ftris.ptr, ctx->n_tris, row_begin, sl.d_bin_lists.ptr, sl.d_bin_counts.ptr,
+                                           sl.d_bin_offsets.ptr, sl.d_bin_total.ptr, bins_x, bins_y, (uint32_t)sl.d_bin_lists.count));
+            RWR_HIP_CHECK(hipMemcpyAsync(sl.h_bin_total, sl.d_bin_total.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            fp.bins = BinGrid{sl.d_bin_lists.ptr, sl.d_bin_counts.ptr, sl.d_bin_offsets.ptr, bins_x, bins_y, (uint32_t)sl.d_bin_lists.count, 1u};
         }
     }
     const bool time_this = ctx->timing_every && (ctx->timing_calls++ % ctx->timing_every == 0) && ctx->timing_pairs < 256;

@@ -161,20 +161,29 @@ hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const rwr_cam
 }
 
 // ---------------------------------------------------------------------------
-// Per-frame screen binning: one workgroup per 64x32-pixel bin walks all faces 256 at a time
-// and writes the ascending list of those its rectangle cannot reject (same ballot + prefix
-// compaction as the render kernels' block level, so lists stay in face order and the
-// lowest-index tie rule survives).
+// Per-frame screen binning, sized by a count pass: k_bin_faces<false> counts, per 64x32-pixel bin, the faces its
+// rectangle cannot reject (one workgroup per bin walks all faces 256 at a time); k_bin_scan turns the counts into
+// list offsets (exclusive scan) and reports the total; k_bin_faces<true> walks the faces again and writes every
+// bin's ascending list at its offset (same ballot + prefix compaction as the render kernels' block level, so lists
+// stay in face order and the lowest-index tie rule survives).  When the total exceeds the buffer's capacity the
+// scan marks every bin kBinNoList — the render kernels then walk the whole scene for this frame, the same
+// pixels — and the context allocates more for the next frames.
+template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_bin_faces(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *__restrict__ lists,
-            uint32_t *__restrict__ counts, uint32_t bins_x, uint32_t cap)
+            uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets, uint32_t bins_x)
 {
     __shared__ uint32_t s_cnt[4];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t bin = blockIdx.y * bins_x + blockIdx.x;
+    uint32_t *__restrict__ out = nullptr;
+    if (FILL) {
+        const uint32_t off = offsets[bin];
+        if (off == kBinNoList) return;   // uniform
+        out = lists + off;
+    }
     const float x0 = (float)(blockIdx.x * kBinW), y0 = (float)(row_begin + blockIdx.y * kBinH);
     const TileRect rect = {x0, y0, x0 + (float)kBinW, y0 + (float)kBinH};
-    uint32_t *__restrict__ out = lists + (size_t)bin * cap;
     uint32_t written = 0;
     for (uint32_t base = 0; base < n_tris; base += 256u) {
         const uint32_t j = base + threadIdx.x;
@@ -190,18 +199,54 @@ k_bin_faces(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_be
             off += (w < wave) ? c : 0u;
             total += c;
         }
-        if (keep) out[written + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;  // written + total <= n_tris <= cap
+        if (FILL && keep) out[written + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;  // within the counted size
         written += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) counts[bin] = written;
+    if (!FILL && threadIdx.x == 0) counts[bin] = written;
+}
+
+// One workgroup: offsets[b] = sum of counts[0..b), *total = the sum; everything kBinNoList when it exceeds capacity.
+__global__ void __launch_bounds__(1024)
+k_bin_scan(const uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets, uint32_t *__restrict__ total_out, uint32_t n_bins,
+           uint32_t capacity)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    if (tid == 0) s_carry = 0u;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_bins; base += 1024u) {
+        const uint32_t b = base + tid;
+        const uint32_t c = b < n_bins ? counts[b] : 0u;
+        uint32_t incl = c;   // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if ((int)lane >= d) incl += up;
+        }
+        if (lane == 63u) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (uint32_t w = 0; w < wave; w++) before += s_wave[w];
+        if (b < n_bins) offsets[b] = before + incl - c;
+        __syncthreads();
+        if (tid == 1023u) s_carry = before + incl;
+        __syncthreads();
+    }
+    const uint32_t total = s_carry;
+    if (tid == 0) *total_out = total;
+    if (total > capacity)   // uniform
+        for (uint32_t b = tid; b < n_bins; b += 1024u) offsets[b] = kBinNoList;
 }
 
 hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *lists,
-                            uint32_t *counts, uint32_t bins_x, uint32_t bins_y, uint32_t cap)
+                            uint32_t *counts, uint32_t *offsets, uint32_t *total_out, uint32_t bins_x, uint32_t bins_y, uint32_t capacity)
 {
     if (n_tris == 0 || bins_x == 0 || bins_y == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_bin_faces, dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts, bins_x, cap);
+    hipLaunchKernelGGL((k_bin_faces<false>), dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts, offsets, bins_x);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, counts, offsets, total_out, bins_x * bins_y, capacity);
+    hipLaunchKernelGGL((k_bin_faces<true>), dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts, offsets, bins_x);
     return hipGetLastError();
 }
 

@@ -145,8 +145,11 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
     const uint32_t *__restrict__ src = nullptr;
     if (CULL && bins_enabled) {
         const uint32_t bin = ((tile_y0 - row_begin) / kBinH) * p.bins.bins_x + blk_x0 / kBinW;
-        n_src = p.bins.counts[bin];
-        src = p.bins.lists + (size_t)bin * p.bins.cap;
+        const uint32_t off = p.bins.offsets[bin];
+        if (off != kBinNoList) {   // (kBinNoList: this frame's lists did not fit; walk the whole scene)
+            n_src = p.bins.counts[bin];
+            src = p.bins.lists + off;
+        }
     }
     n_src = __builtin_amdgcn_readfirstlane(n_src);
     if (CULL) {  // the tile lies outside the screen rectangle of the whole mesh

@@ -117,10 +117,13 @@ static_assert(sizeof(FrameTri) == 64, "FrameTri is 64 B");
 // instead of the whole scene.  Built once per frame, shared by all sample passes.
 constexpr uint32_t kBinW = 64, kBinH = 32;
 struct BinGrid {
-    const uint32_t *lists;   // bins * cap face indices
-    const uint32_t *counts;  // bins
-    uint32_t bins_x, bins_y, cap, enabled;
+    const uint32_t *lists;    // the bins' face lists, back to back (sized by a count pass: count -> exclusive scan -> fill)
+    const uint32_t *counts;   // bins
+    const uint32_t *offsets;  // bins: where a bin's list starts; kBinNoList = "walk the whole scene" (the lists did not
+                              // fit this frame's capacity; the context grows it for the next frames)
+    uint32_t bins_x, bins_y, capacity, enabled;
 };
+constexpr uint32_t kBinNoList = 0xffffffffu;
 
 struct FrameParams {
     rwr_camera_inv_uniform cam;
@@ -250,8 +253,9 @@ hipError_t launch_measure_valu(hipStream_t s, int mode, ulonglong2 *d_out, uint3
 hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const rwr_camera_inv_uniform &cam, uint32_t width,
                               uint32_t height, const CullRec *cull, const TriRecord *tris, uint32_t n_tris,
                               const FrameSetupOut &out);
+// count -> scan -> fill; *total_out (device) receives the entries the frame's lists need
 hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *lists,
-                            uint32_t *counts, uint32_t bins_x, uint32_t bins_y, uint32_t cap);
+                            uint32_t *counts, uint32_t *offsets, uint32_t *total_out, uint32_t bins_x, uint32_t bins_y, uint32_t capacity);
 hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                           const FrameTri *ftris, const float4 *tex, const Targets &tg);
 

@@ -68,8 +68,11 @@ RWR_DEV void primary_visibility(const FrameParams &p, const TriRecord *__restric
         const uint32_t *__restrict__ src = nullptr;
         if (CULL && p.bins.enabled) {
             const uint32_t bin = ((tile_y0 - p.row_begin) / kBinH) * p.bins.bins_x + blk_x0 / kBinW;
-            n_src = p.bins.counts[bin];
-            src = p.bins.lists + (size_t)bin * p.bins.cap;
+            const uint32_t off = p.bins.offsets[bin];
+            if (off != kBinNoList) {   // (kBinNoList: this frame's lists did not fit; walk the whole scene)
+                n_src = p.bins.counts[bin];
+                src = p.bins.lists + off;
+            }
         }
         n_src = __builtin_amdgcn_readfirstlane(n_src);
         // workgroup-uniform: the 32x8 block lies outside the screen rectangle of the whole mesh
