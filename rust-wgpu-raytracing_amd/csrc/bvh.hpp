@@ -33,6 +33,12 @@ static_assert(sizeof(BvhNode4) == 128, "BvhNode4 is 128 B");
 constexpr uint32_t kBvhEmpty = 0xffffffffu;
 constexpr uint32_t kBvhLeafBit = 0x80000000u;
 constexpr uint32_t kBvhMaxLeafDefault = 2;  // the exact hit test costs ~4x a box test: prefer small leaves
+// Deepest 4-wide tree the traversal kernels are sized for: a lane's stack holds up to 3 * depth + 2 entries
+// (38 KiB of LDS per 256-thread workgroup at this depth; the packet traversal's stack is one 64-lane register).
+// A binned-SAH tree over a spatially skewed scene (a dense cluster plus far outliers) can be far deeper than
+// log4(n); such a scene is rebuilt with object-median splits, which bound the depth by ~log2(n) / 2 + 1
+// (12 covers millions of faces).
+constexpr uint32_t kBvhMaxDepth = 12;
 
 struct Bvh {
     std::vector<BvhNode4> nodes;       // nodes[0] is the root (present even for 1 face)
@@ -73,6 +79,7 @@ struct Node2 {
 struct Builder {
     const float *tri;  // n x 9 floats (p0, p1, p2)
     uint32_t max_leaf = kBvhMaxLeafDefault;
+    bool median_only = false;  // object-median splits instead of binned SAH (bounded depth)
     std::vector<Box> tbox;
     std::vector<float> cen;  // n x 3
     std::vector<uint32_t> order;
@@ -101,7 +108,13 @@ struct Builder {
         for (int k = 0; k < 3; k++)
             if (cbox.hi[k] - cbox.lo[k] > ext) { ext = cbox.hi[k] - cbox.lo[k]; axis = k; }
         uint32_t mid = first + count / 2;
-        if (ext > 0.0f && std::isfinite(ext)) {
+        if (median_only) {
+            if (ext > 0.0f && std::isfinite(ext))
+                std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count, [&](uint32_t a, uint32_t b) {
+                    const float ca = cen[3 * (size_t)a + axis], cb = cen[3 * (size_t)b + axis];
+                    return ca < cb || (ca == cb && a < b);
+                });
+        } else if (ext > 0.0f && std::isfinite(ext)) {
             constexpr int kBins = 16;
             Box bb[kBins];
             uint32_t bc[kBins] = {};
@@ -159,12 +172,13 @@ struct Builder {
 }  // namespace bvh_detail
 
 // tri: n faces x 9 floats (world-space p0, p1, p2 as the device holds them).
-inline Bvh build_bvh(const float *tri, uint32_t n, uint32_t max_leaf = kBvhMaxLeafDefault)
+inline Bvh build_bvh_with(const float *tri, uint32_t n, uint32_t max_leaf, bool median_only)
 {
     using namespace bvh_detail;
     Bvh out;
     Builder b;
     b.tri = tri;
+    b.median_only = median_only;
     b.max_leaf = std::min(std::max(max_leaf, 1u), 8u);
     b.tbox.resize(n);
     b.cen.resize((size_t)3 * n);
@@ -263,6 +277,15 @@ inline Bvh build_bvh(const float *tri, uint32_t n, uint32_t max_leaf = kBvhMaxLe
         out.nodes[w.node4] = n4;
     }
     return out;
+}
+
+// Binned SAH; rebuilt with object-median splits when that tree is deeper than kBvhMaxDepth (callers check
+// max_depth again: a scene beyond millions of faces could still exceed it).
+inline Bvh build_bvh(const float *tri, uint32_t n, uint32_t max_leaf = kBvhMaxLeafDefault)
+{
+    Bvh bvh = build_bvh_with(tri, n, max_leaf, false);
+    if (bvh.max_depth > kBvhMaxDepth) bvh = build_bvh_with(tri, n, max_leaf, true);
+    return bvh;
 }
 
 }  // namespace rwr

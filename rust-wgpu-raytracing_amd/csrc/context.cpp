@@ -417,6 +417,9 @@ int rebuild_tris(rwr_context *ctx)
     uint32_t max_leaf = kBvhMaxLeafDefault;
     if (const char *e = std::getenv("RWR_BVH_LEAF")) max_leaf = (uint32_t)std::strtoul(e, nullptr, 10);  // tuning knob
     const Bvh bvh = build_bvh(corners.data(), total, max_leaf);
+    if (bvh.max_depth > kBvhMaxDepth)
+        return set_error(RWR_ERR_UNSUPPORTED, "the scene's BVH is %u levels deep (limit %u): too many faces for the traversal stacks",
+                         bvh.max_depth, kBvhMaxDepth);
     RWR_HIP_CHECK(ctx->d_bvh_nodes.ensure(bvh.nodes.size()));
     RWR_HIP_CHECK(ctx->d_bvh_leaf_faces.ensure(bvh.leaf_faces.size() ? bvh.leaf_faces.size() : 1));
     RWR_HIP_CHECK(hipMemcpy(ctx->d_bvh_nodes.ptr, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode4), hipMemcpyHostToDevice));

@@ -83,3 +83,28 @@ def test_axis_aligned_geometry_and_rays(rwr, orc, ref_loader, gpu_ctx, suzanne):
         want = orc.render_path(cam_inv.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), oparams, orc.make_spheres([]), model)
         _compare(got, want)
     assert got["obj_id"][h // 2, w // 2] == 0     # duplicate faces: the lower index wins the tie
+
+
+def test_skewed_scene_deep_sah_tree_is_rebuilt(rwr, orc, ref_loader, gpu_ctx, suzanne):
+    """A dense cluster plus far outliers: the binned-SAH tree of this 6 000-face scene is 16 levels deep, beyond what
+    the traversal stacks are sized for (csrc/bvh.hpp kBvhMaxDepth = 12), so the context rebuilds it with object-median
+    splits (8 levels).  The BVH kernels — the reference frame with RWR_FLAG_USE_BVH, and bounce rays — must still
+    find the brute-force winner everywhere."""
+    rng = np.random.default_rng(42)
+    n = 6000
+    scale = np.where(np.arange(n) % 50 == 0, 1000.0 * 2.0 ** (np.arange(n) % 13), 1.0)[:, None, None]
+    centers = scale * rng.uniform(-1, 1, (n, 1, 3))
+    model = _soup(ref_loader, rng, n, extent=1.0, tri_size=0.05, tex=suzanne["texture"])
+    model["vertices"]["position"] = (centers + rng.normal(0, 0.05, (n, 3, 3))).reshape(-1, 3).astype(np.float32)
+    w, h = 96, 64
+    cam_inv = rwr.camera_build_inv_uniform(rwr.make_camera(eye=(0.3, 0.2, 1.9), target=(0, 0, 0), aspect=w / h))
+    gpu_ctx.upload_model(model); gpu_ctx.set_instances(None); gpu_ctx.set_spheres(rwr.make_spheres()); gpu_ctx.resize(w, h)
+    gpu_ctx.render(cam_inv, rwr.make_params(flags=rwr.FLAG_AUX_OUTPUTS | rwr.FLAG_USE_BVH))
+    got = gpu_ctx.readback(aux=True)
+    want = orc.render_frame(cam_inv.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), orc.make_spheres(), model)
+    _compare(got, want)
+    assert (got["obj_id"] >= 0).mean() > 0.08
+    gpu_ctx.render(cam_inv, rwr.make_params(spp=2, max_bounces=1, seed=3, flags=rwr.FLAG_AUX_OUTPUTS))
+    got = gpu_ctx.readback(aux=True)
+    want = orc.render_path(cam_inv.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), orc.make_params(2, 1, seed=3), orc.make_spheres(), model)
+    _compare(got, want)
