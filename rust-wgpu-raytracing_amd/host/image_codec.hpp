@@ -113,7 +113,8 @@ struct Huffman {
     }
 };
 
-inline bool inflate_raw(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
+// max_out: the stream may not inflate to more than this (a few bytes of deflate can describe gigabytes)
+inline bool inflate_raw(const uint8_t *src, size_t n, std::vector<uint8_t> &out, size_t max_out)
 {
     static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59,
                                           67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -135,6 +136,7 @@ inline bool inflate_raw(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
             const uint32_t len = hdr[0] | (hdr[1] << 8), nlen = hdr[2] | (hdr[3] << 8);
             if ((len ^ 0xffffu) != nlen) return false;
             const size_t at = out.size();
+            if (at + len > max_out) return false;
             out.resize(at + len);
             if (!br.read_bytes(out.data() + at, len)) return false;
             continue;
@@ -194,7 +196,11 @@ inline bool inflate_raw(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
         for (;;) {
             const int sym = lit.decode(br);
             if (sym < 0) return false;
-            if (sym < 256) { out.push_back((uint8_t)sym); continue; }
+            if (sym < 256) {
+                if (out.size() >= max_out) return false;
+                out.push_back((uint8_t)sym);
+                continue;
+            }
             if (sym == 256) break;
             const int ls = sym - 257;
             if (ls >= 29) return false;
@@ -207,6 +213,7 @@ inline bool inflate_raw(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
             const uint32_t d = dist_base[ds] + eb;
             if (d > out.size()) return false;
             const size_t at = out.size();
+            if (at + len > max_out) return false;
             out.resize(at + len);
             for (uint32_t i = 0; i < len; i++) out[at + i] = out[at + i - d];
         }
@@ -224,11 +231,11 @@ inline uint32_t adler32(const uint8_t *p, size_t n)
     return (b << 16) | a;
 }
 
-inline bool zlib_decompress(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err)
+inline bool zlib_decompress(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err, size_t max_out)
 {
     if (n < 6) { err = "zlib stream too short"; return false; }
     if ((src[0] & 0x0f) != 8 || ((src[0] << 8) | src[1]) % 31 != 0 || (src[1] & 0x20)) { err = "bad zlib header"; return false; }
-    if (!inflate_raw(src + 2, n - 2, out)) { err = "corrupt deflate stream"; return false; }
+    if (!inflate_raw(src + 2, n - 2, out, max_out)) { err = "corrupt deflate stream (or one that inflates beyond the image size)"; return false; }
     return true;
 }
 
@@ -313,9 +320,9 @@ inline bool decode_png(const uint8_t *b, size_t n, Image &img, std::string &err)
     if (ctype == 3 && plte.size() < 3) { err = "palette PNG without PLTE"; return false; }
 
     std::vector<uint8_t> raw;
-    if (!zlib_decompress(idat.data(), idat.size(), raw, err)) return false;
     const size_t bits_pp = (size_t)channels * depth;
     const size_t stride = ((size_t)w * bits_pp + 7) / 8;
+    if (!zlib_decompress(idat.data(), idat.size(), raw, err, (stride + 1) * (size_t)h)) return false;
     const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
     if (raw.size() < (stride + 1) * h) { err = "PNG image data too short"; return false; }
 
@@ -688,6 +695,8 @@ inline bool decode_jpeg(const uint8_t *b, size_t n, Image &img, std::string &err
                 width = (s[3] << 8) | s[4];
                 const int nc = s[5];
                 if ((nc != 1 && nc != 3) || sl < (size_t)(6 + 3 * nc) || width == 0 || height == 0) { err = "unsupported JPEG component count/size"; return false; }
+                // bounded before anything is allocated: textures larger than 16384 on a side are refused at upload anyway
+                if (width > 16384 || height > 16384 || (uint64_t)width * (uint64_t)height > (1ull << 28)) { err = "JPEG too large"; return false; }
                 comps.resize(nc);
                 for (int c = 0; c < nc; c++) {
                     comps[c].id = s[6 + 3 * c];
@@ -710,6 +719,7 @@ inline bool decode_jpeg(const uint8_t *b, size_t n, Image &img, std::string &err
                 break;
             case 0xda: {  // SOS
                 if (!have_sof) { err = "SOS before SOF"; return false; }
+                if (sl < 1) { err = "truncated SOS"; return false; }
                 const int ns = s[0];
                 if (ns != (int)comps.size() || sl < (size_t)(1 + 2 * ns + 3)) { err = "non-interleaved JPEG scans are not supported"; return false; }
                 for (int k = 0; k < ns; k++) {

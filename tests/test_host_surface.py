@@ -154,6 +154,77 @@ def test_decoder_rejects_garbage_and_truncation(rwr):
         rwr.decode_image_rgba8(jpg[:300])
 
 
+def test_decoder_bounds_hostile_inputs(rwr):
+    """Untrusted files: a deflate bomb must not inflate past the image's own size, a JPEG header may not demand gigabytes,
+    a truncated SOS segment may not be read past its end."""
+    import struct
+    import zlib
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+
+    # 8x8 grey PNG whose IDAT inflates to 64 MiB of zeros (stored size: a few tens of KB)
+    bomb = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 8, 8, 8, 0, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(bytes(64 << 20), 9)) + chunk(b"IEND", b"")
+    assert len(bomb) < 200_000
+    with pytest.raises(rwr.RwrError) as ei:
+        rwr.decode_image_rgba8(bomb)
+    assert ei.value.code == rwr.ERR_PARSE
+    # the same header with an honest stream still decodes
+    ok = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 8, 8, 8, 0, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(bytes(9 * 8))) + chunk(b"IEND", b"")
+    assert rwr.decode_image_rgba8(ok).shape == (8, 8, 4)
+
+    jpg = bytearray(open(os.path.join(rwr.RES_DIR, "cube-diffuse.jpg"), "rb").read())
+    sof = jpg.find(b"\xff\xc0")
+    assert sof > 0
+    huge = bytearray(jpg)
+    huge[sof + 5:sof + 9] = b"\xff\xff\xff\xff"          # 65535 x 65535
+    with pytest.raises(rwr.RwrError) as ei:
+        rwr.decode_image_rgba8(bytes(huge))
+    assert ei.value.code == rwr.ERR_PARSE and "too large" in ei.value.message
+    sos = jpg.find(b"\xff\xda")
+    cut = bytes(jpg[:sos]) + b"\xff\xda\x00\x02"          # an SOS segment of length 2: no payload at all, end of file
+    with pytest.raises(rwr.RwrError):
+        rwr.decode_image_rgba8(cut)
+
+
+def test_decoders_under_address_sanitizer(rwr, tmp_path):
+    """The hand-written PNG / JPEG decoders read untrusted files: the two reference textures, truncations and 60 randomly
+    damaged copies go through them in a host build with -fsanitize=address,undefined (tools/asan_codec.cpp)."""
+    import random
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "asan_codec")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        "-I", os.path.join(root, "include"), os.path.join(root, "tools", "asan_codec.cpp"), "-o", exe],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("no sanitizer runtime")
+    assert r.returncode == 0, r.stderr
+    rnd = random.Random(7)
+    files = []
+    for name in ("cube-diffuse.jpg", "suzanne_diffuse.png", "cube-normal.png"):
+        data = open(os.path.join(rwr.RES_DIR, name), "rb").read()
+        files.append(os.path.join(rwr.RES_DIR, name))
+        for k in range(20):
+            b = bytearray(data)
+            if k % 4 == 0:
+                b = b[:rnd.randrange(1, len(b))]
+            else:
+                for _ in range(rnd.randrange(1, 12)):
+                    b[rnd.randrange(len(b))] = rnd.randrange(256)
+            path = str(tmp_path / f"{k}_{name}")
+            open(path, "wb").write(bytes(b))
+            files.append(path)
+    r = subprocess.run([exe] + files, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.count(": ok") >= 3 and "rejected" in r.stdout
+
+
 def test_loader_error_behaviour(rwr, tmp_path):
     with pytest.raises(rwr.RwrError) as ei:                          # anyhow::Error from fs::read_to_string
         rwr.load_model_compute("does_not_exist.obj")
