@@ -134,10 +134,16 @@ enum {
                                        tile, e.g. a distant mesh); same result bit for bit.  The context picks
                                        this kernel by itself when a scene of more than 256 faces projects to
                                        faces far smaller than a tile */
-    RWR_FLAG_ORTHO_RAYS  = 1u << 3  /* every pass generates its rays with pixelToRay_ortho (defined, never called,
+    RWR_FLAG_ORTHO_RAYS  = 1u << 3, /* every pass generates its rays with pixelToRay_ortho (defined, never called,
                                        in all three shaders: triangle_list/compute.wgsl:166-174): origin =
                                        camera.origin + (5 x_nds, 5 y_nds, 0), direction (0, 0, -1).  Reference
                                        frame only (spp 1, no bounce, no RWR_FLAG_USE_BVH) */
+    RWR_FLAG_NORMAL_MAP  = 1u << 4  /* extension: mesh hits are shaded with the normal of their part's normal map
+                                       (rwr_scene_set_normal_map; res/cube.mtl:13 `map_Bump`, which the reference parses
+                                       nowhere: resources.rs:187-213 loads the diffuse texture only and compute.wgsl:226-229
+                                       shades with the flat face normal).  Without the flag — the default — the frame is
+                                       the reference's.  Visibility never changes; bounce rays still leave along the
+                                       geometric normal */
 };
 
 #define RWR_MAX_SPHERES 8
@@ -200,6 +206,17 @@ RWR_API int rwr_scene_add_mesh(rwr_context *ctx,
                                const rwr_material_data *material,
                                const uint8_t *rgba8_srgb, uint32_t tex_w, uint32_t tex_h);
 RWR_API int rwr_scene_commit(rwr_context *ctx);
+
+/* Extension (RWR_FLAG_NORMAL_MAP): the normal map of scene part `part` (0 for a scene uploaded with
+ * rwr_scene_upload_mesh), tex_w*tex_h RGBA8 texels in file order, decoded as LINEAR rgba8unorm (vectors, not
+ * colours), same ClampToEdge / bilinear sampler and texture coordinates as the diffuse texture.  Call after the part
+ * was added (before or after rwr_scene_commit); NULL removes the map.  Shading: tangent frame of the FACE from its
+ * corners and texture coordinates (T = dP/du, B = -dP/dv in sampling space, Gram-Schmidt against the face normal),
+ * n' = normalize(T m.x + B m.y + N m.z), m = 2 texel - 1, in place of the flat normal in compute.wgsl:226-229
+ * (full definition: oracle/rt_oracle.c normal_mapped). */
+RWR_API int rwr_scene_set_normal_map(rwr_context *ctx, uint32_t part, const uint8_t *rgba8_linear, uint32_t tex_w, uint32_t tex_h);
+/* Parts (meshes with faces) added to the scene so far. */
+RWR_API int rwr_scene_part_count(rwr_context *ctx, uint32_t *n_parts);
 
 /* Replaces Sphere::new's uniform, one per analytic sphere pass, composited in
  * array order before the mesh (src/lib.rs:532-534, 1106-1173).  n <= RWR_MAX_SPHERES. */
@@ -343,6 +360,10 @@ RWR_API int rwr_model_part(const rwr_model *model, uint32_t part,
                            const rwr_model_face_small **faces, uint32_t *n_faces,
                            rwr_material_data *material, const uint8_t **rgba8, uint32_t *tex_w, uint32_t *tex_h);
 RWR_API int rwr_scene_upload_model_all(rwr_context *ctx, const rwr_model *model);
+/* Extension: the decoded map_Bump image of a part's material (cube.mtl:13), *rgba8 = NULL when the material names none
+ * or the file is not there.  rwr_scene_upload_model / _all hand it to rwr_scene_set_normal_map; only renders with
+ * RWR_FLAG_NORMAL_MAP look at it. */
+RWR_API int rwr_model_part_normal_map(const rwr_model *model, uint32_t part, const uint8_t **rgba8, uint32_t *tex_w, uint32_t *tex_h);
 
 /* texture::Texture::from_bytes, src/texture.rs:98-106: decode PNG/JPEG bytes to
  * RGBA8.  *out_rgba is malloc'd; free with rwr_free(). */

@@ -237,14 +237,21 @@ def concat_parts(parts: list) -> dict:
     return {"vertices": verts, "faces": np.concatenate(faces) if faces else np.zeros(0, rl.FACE_DTYPE),
             "face_material": np.concatenate(fmat) if fmat else np.zeros(0, np.uint32),
             "materials": np.concatenate([p["material"] for p in parts]),
-            "textures": [np.ascontiguousarray(p["texture"]) for p in parts]}
+            "textures": [np.ascontiguousarray(p["texture"]) for p in parts],
+            "normal_textures": [None if p.get("normal_map") is None else np.ascontiguousarray(p["normal_map"]) for p in parts]}
+
+
+FLAG_NORMAL_MAP = 1 << 4
 
 
 def render_path(cam_inv, screen, params, spheres, model, instances=None, rows=None) -> dict:
-    """The extended integrator (spp / one bounce / instances / several materials) on the CPU, brute
-    force.  `model` is one model dict or a list of them (parts)."""
+    """The extended integrator (spp / one bounce / instances / several materials / normal maps) on the CPU, brute
+    force.  `model` is one model dict or a list of them (parts); a part's optional "normal_map" (RGBA8 array, linear) is
+    used when params has FLAG_NORMAL_MAP."""
     if isinstance(model, (list, tuple)):
         return _render_path_mm(cam_inv, screen, params, spheres, concat_parts(list(model)), instances, rows)
+    if int(params["flags"][0]) & FLAG_NORMAL_MAP and model.get("normal_map") is not None:
+        return _render_path_mm(cam_inv, screen, params, spheres, concat_parts([model]), instances, rows)
     w, h = int(screen["width"][0]), int(screen["height"][0])
     r0, r1 = rows if rows is not None else (0, h)
     color = np.zeros((h, w, 4), np.uint8)
@@ -284,14 +291,18 @@ def _render_path_mm(cam_inv, screen, params, spheres, scene, instances, rows) ->
     inst = None if n_inst == 0 else np.ascontiguousarray(instances, dtype=INSTANCE_DTYPE)
     mats = np.ascontiguousarray(scene["materials"])
     fmat = np.ascontiguousarray(scene["face_material"], dtype=np.uint32)
-    f = lib().or_render_path_mm
+    nts = scene.get("normal_textures") or [None] * n_mat
+    nptrs = (C.c_void_p * n_mat)(*[None if t is None else t.ctypes.data for t in nts])
+    nws = np.array([0 if t is None else t.shape[1] for t in nts], np.uint32)
+    nhs = np.array([0 if t is None else t.shape[0] for t in nts], np.uint32)
+    f = lib().or_render_path_nm
     f.restype = C.c_int
     rc = f(_p(cam_inv), _p(screen), _p(params), _p(spheres), C.c_uint32(len(spheres)),
            _p(scene["vertices"]), C.c_uint32(len(scene["vertices"])), _p(scene["faces"]), C.c_uint32(len(scene["faces"])),
-           _p(inst), C.c_uint32(n_inst), _p(mats), C.c_uint32(n_mat), _p(fmat), ptrs, _p(ws), _p(hs),
+           _p(inst), C.c_uint32(n_inst), _p(mats), C.c_uint32(n_mat), _p(fmat), ptrs, _p(ws), _p(hs), nptrs, _p(nws), _p(nhs),
            C.c_uint32(r0), C.c_uint32(r1), _p(color), _p(depth), _p(color_f), _p(obj_id), _p(hit_t))
     if rc != 0:
-        raise MemoryError("or_render_path_mm")
+        raise MemoryError("or_render_path_nm")
     return {"color": color, "depth": depth, "color_f32": color_f, "obj_id": obj_id, "hit_t": hit_t}
 
 

@@ -229,6 +229,11 @@ def load_model_compute(res_dir: str, file_name: str) -> dict:
     material["diffuse"] = mat0.diffuse
     material["specular"] = mat0.specular
     tex = decode_image_rgba8(os.path.join(res_dir, mat0.diffuse_texture))
+    # map_Bump (cube.mtl:13): the reference never loads it (resources.rs:187-213); decoded here for the normal-mapped
+    # shading EXTENSION only (oracle.render_path with FLAG_NORMAL_MAP).  Linear RGBA8: vectors, not colours.
+    nmap = None
+    if mat0.normal_texture and os.path.exists(os.path.join(res_dir, mat0.normal_texture)):
+        nmap = decode_image_rgba8(os.path.join(res_dir, mat0.normal_texture))
     return {
         "vertices": verts,
         "faces": faces,
@@ -237,6 +242,7 @@ def load_model_compute(res_dir: str, file_name: str) -> dict:
         "material_name": mat0.name,
         "diffuse_texture": mat0.diffuse_texture,
         "normal_texture": mat0.normal_texture,
+        "normal_map": nmap,
         "n_meshes": len(meshes),
         "n_materials": len(materials),
     }

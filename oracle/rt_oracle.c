@@ -295,7 +295,86 @@ typedef struct {
     const uint32_t *face_material; uint32_t n_base_faces;
     const OrMaterial *materials;
     const Tex *texs;
+    /* EXTENSION (normal-mapped shading, see shade_mesh): one optional map per material, consulted only when the
+     * render asked for it (OR_FLAG_NORMAL_MAP). */
+    const Tex *nmaps; int use_nmap;
 } Mesh;
+
+#define OR_FLAG_NORMAL_MAP (1u << 4)
+
+/* Bilinear ClampToEdge fetch like tex_sample_bilinear, but of a LINEAR rgba8unorm texture (texel = byte / 255):
+ * a normal map holds vectors, not colours. */
+static inline v3 tex_sample_bilinear_linear(const Tex *t, float u, float v)
+{
+    float fx = u * (float)t->w - 0.5f, fy = v * (float)t->h - 0.5f;
+    float x0f = floorf(fx), y0f = floorf(fy);
+    float ax = fx - x0f, ay = fy - y0f;
+    float wmax = (float)(t->w - 1u), hmax = (float)(t->h - 1u);
+    uint32_t x0 = (uint32_t)fminf(fmaxf(x0f, 0.0f), wmax), x1 = (uint32_t)fminf(fmaxf(x0f + 1.0f, 0.0f), wmax);
+    uint32_t y0 = (uint32_t)fminf(fmaxf(y0f, 0.0f), hmax), y1 = (uint32_t)fminf(fmaxf(y0f + 1.0f, 0.0f), hmax);
+    const uint8_t *t00 = t->rgba + 4u * ((size_t)y0 * t->w + x0), *t10 = t->rgba + 4u * ((size_t)y0 * t->w + x1);
+    const uint8_t *t01 = t->rgba + 4u * ((size_t)y1 * t->w + x0), *t11 = t->rgba + 4u * ((size_t)y1 * t->w + x1);
+    float w00 = (1.0f - ax) * (1.0f - ay), w10 = ax * (1.0f - ay), w01 = (1.0f - ax) * ay, w11 = ax * ay;
+    float c[3];
+    for (int k = 0; k < 3; k++)
+        c[k] = (float)t00[k] / 255.0f * w00 + (float)t10[k] / 255.0f * w10 + (float)t01[k] / 255.0f * w01 + (float)t11[k] / 255.0f * w11;
+    return V3(c[0], c[1], c[2]);
+}
+
+/* EXTENSION — normal-mapped shading (north_star: "diffuse/normal-map shading"; res/cube.mtl:13 ships `map_Bump
+ * cube-normal.png`, but the reference loads the diffuse texture only, resources.rs:187-213, and compute.wgsl:226-229
+ * shades with the flat face normal).  Definition (this project's; the default frame never takes this path):
+ *   tangent frame of the FACE from its world-space corners and its texture coordinates in sampling space
+ *   (u, 1 - v) (compute.wgsl:224 flips v):  T = dP/du,  B = -dP/dv' (the map's green axis points up the image),
+ *   n^ = normalize(cross(p1 - p0, p2 - p0)) as wound;  t^ = normalize(T - n^ (n^.T)),  b^ = +-cross(n^, t^) with the
+ *   sign that makes b^.B >= 0;  a face with degenerate texture coordinates has t^ = b^ = 0.  The frame is computed
+ *   in double and rounded to f32 once (per-face records on the GPU);
+ *   c = the map, decoded as LINEAR rgba8unorm, bilinear + ClampToEdge at the hit's (u, 1 - v);  m = 2 c - 1;
+ *   n' = normalize(t^ m.x + b^ m.y + s n^ m.z),  s = -1 when the flat normal was flipped towards the ray
+ *   (compute.wgsl:140-142), n' = s n^ when that sum vanishes;
+ *   n' replaces the flat normal in the Lambert and Blinn-Phong terms of compute.wgsl:226-229.  Bounce rays still leave
+ *   along the geometric normal. */
+static inline v3 normal_mapped(const Mesh *m, const OrFace *f, const Tex *nm, float tu, float tv, v3 flat_normal)
+{
+    double p[3][3], uv[3][2];
+    for (int k = 0; k < 3; k++) {
+        const OrVertex *vx = &m->verts[f->indices[k]];
+        for (int c = 0; c < 3; c++) p[k][c] = (double)vx->position[c];
+        uv[k][0] = (double)vx->tex_coords[0];
+        uv[k][1] = 1.0 - (double)vx->tex_coords[1];
+    }
+    double d1[3], d2[3], ng[3];
+    for (int c = 0; c < 3; c++) { d1[c] = p[1][c] - p[0][c]; d2[c] = p[2][c] - p[0][c]; }
+    ng[0] = d1[1] * d2[2] - d1[2] * d2[1]; ng[1] = d1[2] * d2[0] - d1[0] * d2[2]; ng[2] = d1[0] * d2[1] - d1[1] * d2[0];
+    const double nl = sqrt(ng[0] * ng[0] + ng[1] * ng[1] + ng[2] * ng[2]);
+    for (int c = 0; c < 3; c++) ng[c] /= nl;
+    const double du1 = uv[1][0] - uv[0][0], dv1 = uv[1][1] - uv[0][1], du2 = uv[2][0] - uv[0][0], dv2 = uv[2][1] - uv[0][1];
+    const double det = du1 * dv2 - dv1 * du2;
+    double th[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
+    if (det != 0.0 && isfinite(1.0 / det)) {
+        const double r = 1.0 / det;
+        double T[3], B[3], tt[3];
+        for (int c = 0; c < 3; c++) { T[c] = (d1[c] * dv2 - d2[c] * dv1) * r; B[c] = (d2[c] * du1 - d1[c] * du2) * -r; }
+        const double nt = ng[0] * T[0] + ng[1] * T[1] + ng[2] * T[2];
+        for (int c = 0; c < 3; c++) tt[c] = T[c] - ng[c] * nt;
+        const double tl = sqrt(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]);
+        if (tl > 0.0 && isfinite(tl)) {
+            for (int c = 0; c < 3; c++) th[c] = tt[c] / tl;
+            bh[0] = ng[1] * th[2] - ng[2] * th[1]; bh[1] = ng[2] * th[0] - ng[0] * th[2]; bh[2] = ng[0] * th[1] - ng[1] * th[0];
+            if (bh[0] * B[0] + bh[1] * B[1] + bh[2] * B[2] < 0.0) { bh[0] = -bh[0]; bh[1] = -bh[1]; bh[2] = -bh[2]; }
+        }
+    }
+    const v3 t_hat = V3((float)th[0], (float)th[1], (float)th[2]), b_hat = V3((float)bh[0], (float)bh[1], (float)bh[2]);
+    const v3 n_hat = V3((float)ng[0], (float)ng[1], (float)ng[2]);
+    const float s = dot3(flat_normal, n_hat) < 0.0f ? -1.0f : 1.0f;
+    const v3 c = tex_sample_bilinear_linear(nm, tu, tv);
+    const v3 mm = V3(2.0f * c.x - 1.0f, 2.0f * c.y - 1.0f, 2.0f * c.z - 1.0f);
+    v3 n = V3(t_hat.x * mm.x + b_hat.x * mm.y + s * n_hat.x * mm.z, t_hat.y * mm.x + b_hat.y * mm.y + s * n_hat.y * mm.z,
+              t_hat.z * mm.x + b_hat.z * mm.y + s * n_hat.z * mm.z);
+    const float l2 = dot3(n, n);
+    if (!(l2 > 1e-20f)) return scale3(n_hat, s);
+    return scale3(n, 1.0f / sqrtf(l2));
+}
 
 /* Local shading of a mesh hit — triangle_list/compute.wgsl:217-234.
  * Returns final_color.rgb (alpha is 2.0); *albedo receives the filtered texel
@@ -312,19 +391,22 @@ static inline v3 shade_mesh(const Mesh *m, uint32_t i_min, const HitRecord *h, R
     tv = 1.0f - tv;
     const OrMaterial *mat = m->material;
     const Tex *tx = &m->tex;
+    uint32_t mid = 0;
     if (m->face_material) {
-        const uint32_t mid = m->face_material[i_min % m->n_base_faces];
+        mid = m->face_material[i_min % m->n_base_faces];
         mat = &m->materials[mid];
         tx = &m->texs[mid];
     }
     v3 tex = tex_sample_bilinear(tx, tu, tv);
     if (albedo) *albedo = tex;
+    v3 normal = h->normal;
+    if (m->use_nmap && m->nmaps && m->nmaps[mid].rgba) normal = normal_mapped(m, f, &m->nmaps[mid], tu, tv, h->normal);  /* extension */
 
     v3 nl = neg3(normalize3(kLightDir));
-    float ndl = fmaxf(0.0f, dot3(h->normal, nl));
+    float ndl = fmaxf(0.0f, dot3(normal, nl));
     v3 diffuse = scale3(tex, ndl);
     v3 half_dir = normalize3(sub3(nl, ray.direction));
-    float sp = powf(fmaxf(0.0f, dot3(half_dir, h->normal)), 32.0f);
+    float sp = powf(fmaxf(0.0f, dot3(half_dir, normal)), 32.0f);
     v3 specular = V3(mat->specular[0] * sp, mat->specular[1] * sp, mat->specular[2] * sp);
     v3 out;
     out.x = (mat->ambient[0] + diffuse.x) + specular.x;
@@ -429,7 +511,7 @@ OR_API void or_mesh_pass(const OrCameraInvUniform *cam, const OrScreen *screen,
     Mesh m;
     m.verts = verts; m.n_verts = n_verts; m.faces = faces; m.n_faces = n_faces; m.material = material;
     m.tex.rgba = tex_rgba8; m.tex.w = tex_w; m.tex.h = tex_h;
-    m.face_material = NULL; m.n_base_faces = n_faces; m.materials = NULL; m.texs = NULL;
+    m.face_material = NULL; m.n_base_faces = n_faces; m.materials = NULL; m.texs = NULL; m.nmaps = NULL; m.use_nmap = 0;
     build_srgb_lut(m.tex.lut);
     OrAux aux = {color_u8, color_f32, obj_id, hit_t};
     const int W = (int)screen->width, H = (int)screen->height;
@@ -602,7 +684,7 @@ OR_API int or_render_frame_ex(const OrCameraInvUniform *cam, const OrScreen *scr
         Mesh m;
         m.verts = verts; m.n_verts = n_verts; m.faces = faces; m.n_faces = n_faces; m.material = material;
         m.tex.rgba = tex_rgba8; m.tex.w = tex_w; m.tex.h = tex_h;
-        m.face_material = NULL; m.n_base_faces = n_faces; m.materials = NULL; m.texs = NULL;
+        m.face_material = NULL; m.n_base_faces = n_faces; m.materials = NULL; m.texs = NULL; m.nmaps = NULL; m.use_nmap = 0; m.nmaps = NULL; m.use_nmap = 0;
         build_srgb_lut(m.tex.lut);
 #pragma omp parallel for schedule(dynamic, 4)
         for (int y = 0; y < H; y++) {
@@ -733,23 +815,27 @@ static inline v3 shade_any(const Scene *sc, int32_t id, const HitRecord *h, Ray 
  * texture (tex_ptrs[k], tex_ws[k], tex_hs[k]) of that material; face_material == NULL means
  * "everything uses material 0".  Faces of all parts are one flat list (part order, then face
  * order), so the lowest-index tie rule extends across parts. */
-OR_API int or_render_path_mm(const OrCameraInvUniform *cam, const OrScreen *screen, const OrRenderParams *params,
-                             const OrSphere *spheres, uint32_t n_spheres,
-                             const OrVertex *verts, uint32_t n_verts, const OrFace *faces, uint32_t n_faces,
-                             const OrInstance *instances, uint32_t n_instances,
-                             const OrMaterial *materials, uint32_t n_materials, const uint32_t *face_material,
-                             const uint8_t *const *tex_ptrs, const uint32_t *tex_ws, const uint32_t *tex_hs,
-                             uint32_t row_begin, uint32_t row_end,
-                             uint8_t *color_u8, float *depth_out, float *color_f32, int32_t *obj_id, float *hit_t)
+static int render_path_core(const OrCameraInvUniform *cam, const OrScreen *screen, const OrRenderParams *params,
+                            const OrSphere *spheres, uint32_t n_spheres,
+                            const OrVertex *verts, uint32_t n_verts, const OrFace *faces, uint32_t n_faces,
+                            const OrInstance *instances, uint32_t n_instances,
+                            const OrMaterial *materials, uint32_t n_materials, const uint32_t *face_material,
+                            const uint8_t *const *tex_ptrs, const uint32_t *tex_ws, const uint32_t *tex_hs,
+                            const uint8_t *const *nmap_ptrs, const uint32_t *nmap_ws, const uint32_t *nmap_hs,
+                            uint32_t row_begin, uint32_t row_end,
+                            uint8_t *color_u8, float *depth_out, float *color_f32, int32_t *obj_id, float *hit_t)
 {
     const OrMaterial *material = materials;
     const uint8_t *tex_rgba8 = n_materials ? tex_ptrs[0] : NULL;
     const uint32_t tex_w = n_materials ? tex_ws[0] : 0u, tex_h = n_materials ? tex_hs[0] : 0u;
     Tex *texs = (Tex *)calloc(n_materials ? n_materials : 1u, sizeof(Tex));
     if (!texs) return -1;
+    Tex *nmaps = (Tex *)calloc(n_materials ? n_materials : 1u, sizeof(Tex));
+    if (!nmaps) { free(texs); return -1; }
     for (uint32_t k = 0; k < n_materials; k++) {
         texs[k].rgba = tex_ptrs[k]; texs[k].w = tex_ws[k]; texs[k].h = tex_hs[k];
         build_srgb_lut(texs[k].lut);
+        if (nmap_ptrs && nmap_ptrs[k] && nmap_ws[k] && nmap_hs[k]) { nmaps[k].rgba = nmap_ptrs[k]; nmaps[k].w = nmap_ws[k]; nmaps[k].h = nmap_hs[k]; }
     }
     const uint32_t W = screen->width, H = screen->height;
     if (row_end > H) row_end = H;
@@ -764,10 +850,12 @@ OR_API int or_render_path_mm(const OrCameraInvUniform *cam, const OrScreen *scre
     sc.mesh.n_base_faces = n_faces ? n_faces : 1u;
     sc.mesh.materials = materials;
     sc.mesh.texs = texs;
+    sc.mesh.nmaps = nmaps;
+    sc.mesh.use_nmap = (params->flags & OR_FLAG_NORMAL_MAP) != 0u;
     if (n_instances && n_faces) {
         wverts = (OrVertex *)malloc((size_t)n_verts * n_instances * sizeof(OrVertex));
         wfaces = (OrFace *)malloc((size_t)n_faces * n_instances * sizeof(OrFace));
-        if (!wverts || !wfaces) { free(wverts); free(wfaces); free(texs); return -1; }
+        if (!wverts || !wfaces) { free(wverts); free(wfaces); free(texs); free(nmaps); return -1; }
         for (uint32_t k = 0; k < n_instances; k++) {
             for (uint32_t i = 0; i < n_verts; i++) {
                 OrVertex v = verts[i];
@@ -860,8 +948,40 @@ OR_API int or_render_path_mm(const OrCameraInvUniform *cam, const OrScreen *scre
             if (hit_t) hit_t[idx] = t0;
         }
     }
-    free(wverts); free(wfaces); free(texs);
+    free(wverts); free(wfaces); free(texs); free(nmaps);
     return 0;
+}
+
+/* Multi-material form (see render_path_core). */
+OR_API int or_render_path_mm(const OrCameraInvUniform *cam, const OrScreen *screen, const OrRenderParams *params,
+                             const OrSphere *spheres, uint32_t n_spheres,
+                             const OrVertex *verts, uint32_t n_verts, const OrFace *faces, uint32_t n_faces,
+                             const OrInstance *instances, uint32_t n_instances,
+                             const OrMaterial *materials, uint32_t n_materials, const uint32_t *face_material,
+                             const uint8_t *const *tex_ptrs, const uint32_t *tex_ws, const uint32_t *tex_hs,
+                             uint32_t row_begin, uint32_t row_end,
+                             uint8_t *color_u8, float *depth_out, float *color_f32, int32_t *obj_id, float *hit_t)
+{
+    return render_path_core(cam, screen, params, spheres, n_spheres, verts, n_verts, faces, n_faces, instances, n_instances, materials,
+                            n_materials, face_material, tex_ptrs, tex_ws, tex_hs, NULL, NULL, NULL, row_begin, row_end, color_u8,
+                            depth_out, color_f32, obj_id, hit_t);
+}
+
+/* ... with one optional normal map per material (nmap_ptrs[k] == NULL: none), used when params->flags has
+ * OR_FLAG_NORMAL_MAP (extension: normal_mapped()). */
+OR_API int or_render_path_nm(const OrCameraInvUniform *cam, const OrScreen *screen, const OrRenderParams *params,
+                             const OrSphere *spheres, uint32_t n_spheres,
+                             const OrVertex *verts, uint32_t n_verts, const OrFace *faces, uint32_t n_faces,
+                             const OrInstance *instances, uint32_t n_instances,
+                             const OrMaterial *materials, uint32_t n_materials, const uint32_t *face_material,
+                             const uint8_t *const *tex_ptrs, const uint32_t *tex_ws, const uint32_t *tex_hs,
+                             const uint8_t *const *nmap_ptrs, const uint32_t *nmap_ws, const uint32_t *nmap_hs,
+                             uint32_t row_begin, uint32_t row_end,
+                             uint8_t *color_u8, float *depth_out, float *color_f32, int32_t *obj_id, float *hit_t)
+{
+    return render_path_core(cam, screen, params, spheres, n_spheres, verts, n_verts, faces, n_faces, instances, n_instances, materials,
+                            n_materials, face_material, tex_ptrs, tex_ws, tex_hs, nmap_ptrs, nmap_ws, nmap_hs, row_begin, row_end,
+                            color_u8, depth_out, color_f32, obj_id, hit_t);
 }
 
 OR_API int or_render_path(const OrCameraInvUniform *cam, const OrScreen *screen, const OrRenderParams *params,

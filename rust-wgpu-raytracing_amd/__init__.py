@@ -42,6 +42,7 @@ assert (CAMERA_INV_DTYPE.itemsize, VERTEX_DTYPE.itemsize, FACE_DTYPE.itemsize, M
 FLAG_AUX_OUTPUTS, FLAG_NO_CULL, FLAG_USE_BVH = 1, 2, 4
 # internal debug flags (csrc/rwr_internal.h, not part of include/rwr_hip.h)
 FLAG_ORTHO_RAYS = 1 << 3
+FLAG_NORMAL_MAP = 1 << 4
 FLAG_DEBUG_COUNTS, FLAG_ONE_PIXEL_PER_LANE = 1 << 16, 1 << 17
 KEY_FORWARD, KEY_BACKWARD, KEY_LEFT, KEY_RIGHT, KEY_UP, KEY_DOWN = 1, 2, 4, 8, 16, 32
 OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NOT_READY, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
@@ -97,7 +98,8 @@ def lib() -> C.CDLL:
         "rwr_scene_upload_mesh": [vp, vp, u32, vp, u32, vp, vp, u32, u32],
         "rwr_scene_clear": [vp], "rwr_scene_add_mesh": [vp, vp, u32, vp, u32, vp, vp, u32, u32], "rwr_scene_commit": [vp],
         "rwr_model_part_count": [vp, vp], "rwr_model_part": [vp, u32, vp, vp, vp, vp, vp, vp, vp, vp],
-        "rwr_scene_upload_model_all": [vp, vp],
+        "rwr_scene_upload_model_all": [vp, vp], "rwr_model_part_normal_map": [vp, u32, vp, vp, vp],
+        "rwr_scene_set_normal_map": [vp, u32, vp, u32, u32], "rwr_scene_part_count": [vp, vp],
         "rwr_scene_set_spheres": [vp, vp, u32], "rwr_scene_set_triangles": [vp, vp, u32], "rwr_scene_set_instances": [vp, vp, u32],
         "rwr_resize": [vp, vp], "rwr_render": [vp, vp, vp], "rwr_render_rows": [vp, vp, vp, u32, u32],
         "rwr_synchronize": [vp], "rwr_readback": [vp, vp, vp, vp, vp, vp], "rwr_get_device_targets": [vp, vp, vp],
@@ -220,10 +222,21 @@ def load_model_compute(file_name: str, res_dir: str = RES_DIR) -> dict:
         faces = np.frombuffer(C.string_at(L.rwr_model_faces(h), n_faces * 16), dtype=FACE_DTYPE).copy()
         material = np.frombuffer(C.string_at(L.rwr_model_material(h), 48), dtype=MATERIAL_DTYPE).copy()
         tex = np.frombuffer(C.string_at(L.rwr_model_texture_rgba8(h), tw * th * 4), dtype=np.uint8).reshape(th, tw, 4).copy()
+        nmap = _part_normal_map(L, h, 0)
     finally:
         L.rwr_model_free(h)
-    return {"vertices": verts, "faces": faces, "material": material, "texture": tex,
+    return {"vertices": verts, "faces": faces, "material": material, "texture": tex, "normal_map": nmap,
             "n_meshes": n_meshes, "n_materials": n_materials}
+
+
+def _part_normal_map(L, h, part):
+    """The decoded map_Bump image of a part's material (extension), or None."""
+    pn, nw, nh = C.c_void_p(), C.c_uint32(), C.c_uint32()
+    _check(L.rwr_model_part_normal_map(h, part, C.byref(pn), C.byref(nw), C.byref(nh)))
+    if not pn.value:
+        return None
+    return np.frombuffer(C.string_at(pn, nw.value * nh.value * 4), dtype=np.uint8).reshape(nh.value, nw.value, 4).copy()
+
 
 
 def load_model_parts(file_name: str, res_dir: str = RES_DIR) -> list:
@@ -245,6 +258,7 @@ def load_model_parts(file_name: str, res_dir: str = RES_DIR) -> list:
                 "faces": np.frombuffer(C.string_at(pf, nf.value * 16), dtype=FACE_DTYPE).copy(),
                 "material": mat,
                 "texture": np.frombuffer(C.string_at(pt, tw.value * th.value * 4), dtype=np.uint8).reshape(th.value, tw.value, 4).copy(),
+                "normal_map": _part_normal_map(L, h, i),
             })
     finally:
         L.rwr_model_free(h)
@@ -320,6 +334,16 @@ class Context:
 
     def upload_model(self, model: dict):
         self.upload_mesh(model["vertices"], model["faces"], model["material"], model["texture"])
+        if model.get("normal_map") is not None and len(model["faces"]):
+            self.set_normal_map(0, model["normal_map"])
+
+    def set_normal_map(self, part: int, rgba8_linear):
+        """Extension: the normal map (RGBA8, linear) of scene part `part`; None removes it.  Used by FLAG_NORMAL_MAP renders."""
+        if rgba8_linear is None:
+            _check(lib().rwr_scene_set_normal_map(self._h, part, None, 0, 0))
+            return
+        t = np.ascontiguousarray(rgba8_linear, dtype=np.uint8)
+        _check(lib().rwr_scene_set_normal_map(self._h, part, _p(t), t.shape[1], t.shape[0]))
 
     def upload_parts(self, parts: list):
         """Extension: a scene of several meshes, each with its own material and texture."""
@@ -332,6 +356,10 @@ class Context:
             th, tw = texture.shape[:2]
             _check(lib().rwr_scene_add_mesh(self._h, _p(vertices), len(vertices), _p(faces), len(faces), _p(material),
                                             _p(texture), tw, th))
+            if m.get("normal_map") is not None and len(faces):
+                n = C.c_uint32()
+                _check(lib().rwr_scene_part_count(self._h, C.byref(n)))
+                self.set_normal_map(n.value - 1, m["normal_map"])
         _check(lib().rwr_scene_commit(self._h))
 
     def set_spheres(self, spheres):

@@ -112,6 +112,8 @@ struct rwr_context {
     DeviceBuffer<TriRecord> d_tris;
     DeviceBuffer<ShadeRec> d_shade;
     DeviceBuffer<CullRec> d_cull;
+    DeviceBuffer<TangentRec> d_tangent;                 // per-face tangent frames (normal-mapped shading)
+    std::vector<DeviceBuffer<float4>> d_nmaps;          // one optional normal map per scene part (linear texels)
     uint32_t bin_min_faces = 256;                       // tunable: RWR_BIN_MIN_FACES
     uint32_t bin_min_capacity = 65536;                  // tunable: RWR_BIN_CAPACITY (entries the bin lists start with)
     bool force_one_pixel = false;                       // debug: RWR_ONE_PIXEL_PER_LANE=1
@@ -395,8 +397,10 @@ int rebuild_tris(rwr_context *ctx)
     RWR_HIP_CHECK(ctx->d_tris.ensure(total));
     RWR_HIP_CHECK(ctx->d_shade.ensure(total));
     RWR_HIP_CHECK(ctx->d_cull.ensure(total));
+    RWR_HIP_CHECK(ctx->d_tangent.ensure(total));
     RWR_HIP_CHECK(launch_prebake(ctx->stream, ctx->d_verts.ptr, ctx->d_faces.ptr, ctx->d_face_mat.ptr, ctx->n_faces, ctx->d_instances.ptr,
-                                 ctx->n_instances, ctx->d_materials.ptr, ctx->d_tris.ptr, ctx->d_shade.ptr, ctx->d_cull.ptr));
+                                 ctx->n_instances, ctx->d_materials.ptr, ctx->d_tris.ptr, ctx->d_shade.ptr, ctx->d_cull.ptr,
+                                 ctx->d_tangent.ptr));
     // BVH for incoherent rays, built on the host from the device's own world-space corners
     // (so instancing arithmetic happens in exactly one place, k_prebake)
     std::vector<CullRec> host_cull(total);
@@ -507,7 +511,8 @@ void rwr_ctx_destroy(rwr_context *ctx)
         ctx->d_wf_dbg.release();
     }
     ctx->d_verts.release(); ctx->d_faces.release(); ctx->d_instances.release();
-    ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release();
+    ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release(); ctx->d_tangent.release();
+    for (auto &t : ctx->d_nmaps) t.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
     ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wave_total.release(); ctx->d_wf_fix.release(); ctx->d_pool_info.release(); ctx->d_wf_live.release(); ctx->d_pool_list.release(); for (auto &t : ctx->d_texs) t.release();
     ctx->d_face_mat.release(); ctx->d_materials.release();
@@ -559,6 +564,8 @@ int rwr_scene_clear(rwr_context *ctx)
     ctx->st_verts.clear(); ctx->st_faces.clear(); ctx->st_face_mat.clear(); ctx->st_materials.clear();
     for (auto &t : ctx->d_texs) t.release();
     ctx->d_texs.clear();
+    for (auto &t : ctx->d_nmaps) t.release();
+    ctx->d_nmaps.clear();
     ctx->have_mesh = false;
     ctx->n_faces = ctx->n_verts = ctx->n_tris = 0;
     return RWR_OK;
@@ -616,7 +623,9 @@ int rwr_scene_add_mesh(rwr_context *ctx, const rwr_model_vertex_small *verts, ui
     for (int k = 0; k < 3; k++) { M.ambient[k] = material->ambient[k]; M.specular[k] = material->specular[k]; }
     M.tex_w = tex_w; M.tex_h = tex_h; M.tex = tex.ptr;
     M.wmax = (float)(tex_w - 1u); M.hmax = (float)(tex_h - 1u);
+    M.nmap = nullptr; M.nmap_w = M.nmap_h = 0u;
     ctx->st_materials.push_back(M);
+    ctx->d_nmaps.emplace_back();
     if (mid == 0) ctx->material = *material;
     return RWR_OK;
 }
@@ -648,6 +657,42 @@ int rwr_scene_commit(rwr_context *ctx)
     const int rc = rebuild_tris(ctx);
     if (rc != RWR_OK) return rc;
     RWR_HIP_CHECK(ensure_frame_buffers(ctx));
+    return RWR_OK;
+}
+
+int rwr_scene_part_count(rwr_context *ctx, uint32_t *n_parts)
+{
+    if (!ctx || !n_parts) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *n_parts = (uint32_t)ctx->st_materials.size();
+    return RWR_OK;
+}
+
+int rwr_scene_set_normal_map(rwr_context *ctx, uint32_t part, const uint8_t *rgba8_linear, uint32_t tex_w, uint32_t tex_h)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (part >= ctx->st_materials.size()) return set_error(RWR_ERR_INVALID_ARGUMENT, "part %u: the scene has %zu parts", part, ctx->st_materials.size());
+    if (rgba8_linear && (tex_w == 0 || tex_h == 0)) return set_error(RWR_ERR_INVALID_ARGUMENT, "empty normal map");
+    if (tex_w > kMaxTextureDim || tex_h > kMaxTextureDim)
+        return set_error(RWR_ERR_INVALID_ARGUMENT, "normal map %ux%u larger than %ux%u", tex_w, tex_h, kMaxTextureDim, kMaxTextureDim);
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(sync_all(ctx));
+    DeviceBuffer<float4> &tex = ctx->d_nmaps[part];
+    MaterialRec &M = ctx->st_materials[part];
+    if (!rgba8_linear) {
+        tex.release();
+        M.nmap = nullptr; M.nmap_w = M.nmap_h = 0u;
+    } else {
+        tex.release();
+        RWR_HIP_CHECK(tex.ensure((size_t)tex_w * tex_h));
+        std::vector<float4> lin((size_t)tex_w * tex_h);
+        for (size_t i = 0; i < lin.size(); i++)   // rgba8unorm, NOT sRGB: a normal map holds vectors
+            lin[i] = make_float4((float)rgba8_linear[4 * i] / 255.0f, (float)rgba8_linear[4 * i + 1] / 255.0f,
+                                 (float)rgba8_linear[4 * i + 2] / 255.0f, (float)rgba8_linear[4 * i + 3] / 255.0f);
+        RWR_HIP_CHECK(hipMemcpy(tex.ptr, lin.data(), lin.size() * sizeof(float4), hipMemcpyHostToDevice));
+        M.nmap = tex.ptr; M.nmap_w = tex_w; M.nmap_h = tex_h;
+    }
+    if (ctx->have_mesh && ctx->d_materials.ptr && ctx->d_materials.count >= ctx->st_materials.size())   // already committed: refresh the device copy
+        RWR_HIP_CHECK(hipMemcpy(ctx->d_materials.ptr, ctx->st_materials.data(), ctx->st_materials.size() * sizeof(MaterialRec), hipMemcpyHostToDevice));
     return RWR_OK;
 }
 
@@ -789,6 +834,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     }
     fp.materials = ctx->d_materials.ptr;
     fp.n_materials = (uint32_t)ctx->st_materials.size();
+    fp.tangents = ctx->d_tangent.ptr;
     const float4 *tex0 = ctx->d_texs.empty() ? nullptr : ctx->d_texs[0].ptr;
     Targets tg{sl.d_color.ptr, sl.d_depth.ptr, aux ? sl.d_color_f32.ptr : nullptr,
                aux ? sl.d_obj_id.ptr : nullptr, aux ? sl.d_hit_t.ptr : nullptr};

@@ -123,6 +123,19 @@ int rwr_model_part(const rwr_model *model, uint32_t part, const rwr_model_vertex
     return RWR_OK;
 }
 
+int rwr_model_part_normal_map(const rwr_model *model, uint32_t part, const uint8_t **rgba8, uint32_t *tex_w, uint32_t *tex_h)
+{
+    if (!model || !rgba8 || !tex_w || !tex_h) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    const auto &m = model->model;
+    if (part >= m.meshes.size()) return set_error(RWR_ERR_INVALID_ARGUMENT, "part %u out of range (%zu meshes)", part, m.meshes.size());
+    if (m.meshes[part].material >= m.materials.size()) return set_error(RWR_ERR_PARSE, "mesh %u references a missing material", part);
+    const auto &nm = m.materials[m.meshes[part].material].normal_texture;
+    *rgba8 = nm.rgba.empty() ? nullptr : nm.rgba.data();
+    *tex_w = nm.width;
+    *tex_h = nm.height;
+    return RWR_OK;
+}
+
 int rwr_scene_upload_model_all(rwr_context *ctx, const rwr_model *model)
 {
     if (!ctx || !model) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -132,7 +145,16 @@ int rwr_scene_upload_model_all(rwr_context *ctx, const rwr_model *model)
         uint32_t nv, nf, tw, th;
         rwr_material_data md;
         rc = rwr_model_part(model, i, &v, &nv, &f, &nf, &md, &t, &tw, &th);
+        if (rc == RWR_OK && nf == 0) continue;   // an empty mesh adds no part
         if (rc == RWR_OK) rc = rwr_scene_add_mesh(ctx, v, nv, f, nf, &md, t, tw, th);
+        const uint8_t *nm = nullptr;
+        uint32_t nw = 0, nh = 0;
+        if (rc == RWR_OK) rc = rwr_model_part_normal_map(model, i, &nm, &nw, &nh);
+        if (rc == RWR_OK && nm) {   // the part just added is the scene's last
+            uint32_t n_parts = 0;
+            rc = rwr_scene_part_count(ctx, &n_parts);
+            if (rc == RWR_OK) rc = rwr_scene_set_normal_map(ctx, n_parts - 1u, nm, nw, nh);
+        }
     }
     if (rc == RWR_OK) rc = rwr_scene_commit(ctx);
     return rc;
@@ -143,8 +165,11 @@ int rwr_scene_upload_model(rwr_context *ctx, const rwr_model *model)
     if (!ctx || !model) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
     const auto &mesh = model->model.meshes[0];
     const auto &tex = model->model.materials[0].diffuse_texture;
-    return rwr_scene_upload_mesh(ctx, mesh.vertex_buffer.data(), (uint32_t)mesh.vertex_buffer.size(), mesh.index_buffer.data(),
-                                 (uint32_t)mesh.index_buffer.size(), rwr_model_material(model), tex.rgba.data(), tex.width, tex.height);
+    int rc = rwr_scene_upload_mesh(ctx, mesh.vertex_buffer.data(), (uint32_t)mesh.vertex_buffer.size(), mesh.index_buffer.data(),
+                                   (uint32_t)mesh.index_buffer.size(), rwr_model_material(model), tex.rgba.data(), tex.width, tex.height);
+    const auto &nm = model->model.materials[0].normal_texture;   // extension: only RWR_FLAG_NORMAL_MAP renders look at it
+    if (rc == RWR_OK && !nm.rgba.empty() && !mesh.index_buffer.empty()) rc = rwr_scene_set_normal_map(ctx, 0, nm.rgba.data(), nm.width, nm.height);
+    return rc;
 }
 
 int rwr_decode_image_rgba8(const uint8_t *bytes, size_t n_bytes, uint8_t **out_rgba, uint32_t *out_w, uint32_t *out_h)

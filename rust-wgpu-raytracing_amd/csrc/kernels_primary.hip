@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256)
 k_prebake(const rwr_model_vertex_small *__restrict__ verts, const rwr_model_face_small *__restrict__ faces,
           const uint32_t *__restrict__ face_material, uint32_t n_faces, const rwr_instance_raw *__restrict__ instances,
           uint32_t n_instances, const MaterialRec *__restrict__ materials,
-          TriRecord *__restrict__ tris, ShadeRec *__restrict__ shade, CullRec *__restrict__ cull)
+          TriRecord *__restrict__ tris, ShadeRec *__restrict__ shade, CullRec *__restrict__ cull, TangentRec *__restrict__ tangents)
 {
     const uint32_t total = n_faces * (n_instances ? n_instances : 1u);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,6 +88,35 @@ k_prebake(const rwr_model_vertex_small *__restrict__ verts, const rwr_model_face
     S.material = mat;
     S.pad = 0.0f;
     shade[i] = S;
+    {
+        // Tangent frame for normal-mapped shading (extension; oracle/rt_oracle.c normal_mapped): T = dP/du, B = -dP/dv' in
+        // the sampling space (u, v' = 1 - v), Gram-Schmidt against the unit normal as wound, in double.
+        const double d1[3] = {(double)p1.x - p0.x, (double)p1.y - p0.y, (double)p1.z - p0.z};
+        const double d2[3] = {(double)p2.x - p0.x, (double)p2.y - p0.y, (double)p2.z - p0.z};
+        double ng[3] = {d1[1] * d2[2] - d1[2] * d2[1], d1[2] * d2[0] - d1[0] * d2[2], d1[0] * d2[1] - d1[1] * d2[0]};
+        const double nl = sqrt(ng[0] * ng[0] + ng[1] * ng[1] + ng[2] * ng[2]);
+        ng[0] /= nl; ng[1] /= nl; ng[2] /= nl;
+        const double du1 = u1 - u0, dv1 = (1.0 - w1) - (1.0 - w0), du2 = u2 - u0, dv2 = (1.0 - w2) - (1.0 - w0);
+        const double det = du1 * dv2 - dv1 * du2;
+        double th[3] = {0.0, 0.0, 0.0}, bh[3] = {0.0, 0.0, 0.0};
+        if (det != 0.0 && isfinite(1.0 / det)) {
+            const double r = 1.0 / det;
+            double T[3], B[3], tt[3];
+            for (int c = 0; c < 3; c++) { T[c] = (d1[c] * dv2 - d2[c] * dv1) * r; B[c] = (d2[c] * du1 - d1[c] * du2) * -r; }
+            const double nt = ng[0] * T[0] + ng[1] * T[1] + ng[2] * T[2];
+            for (int c = 0; c < 3; c++) tt[c] = T[c] - ng[c] * nt;
+            const double tl = sqrt(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]);
+            if (tl > 0.0 && isfinite(tl)) {
+                for (int c = 0; c < 3; c++) th[c] = tt[c] / tl;
+                bh[0] = ng[1] * th[2] - ng[2] * th[1]; bh[1] = ng[2] * th[0] - ng[0] * th[2]; bh[2] = ng[0] * th[1] - ng[1] * th[0];
+                if (bh[0] * B[0] + bh[1] * B[1] + bh[2] * B[2] < 0.0) { bh[0] = -bh[0]; bh[1] = -bh[1]; bh[2] = -bh[2]; }
+            }
+        }
+        TangentRec G;
+        G.t[0] = (float)th[0]; G.t[1] = (float)th[1]; G.t[2] = (float)th[2]; G.pad0 = 0.0f;
+        G.b[0] = (float)bh[0]; G.b[1] = (float)bh[1]; G.b[2] = (float)bh[2]; G.pad1 = 0.0f;
+        tangents[i] = G;
+    }
     CullRec R;
     R.p0[0] = p0.x; R.p0[1] = p0.y; R.p0[2] = p0.z;
     R.p1[0] = p1.x; R.p1[1] = p1.y; R.p1[2] = p1.z;
@@ -98,12 +127,13 @@ k_prebake(const rwr_model_vertex_small *__restrict__ verts, const rwr_model_face
 
 hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, const rwr_model_face_small *faces,
                           const uint32_t *face_material, uint32_t n_faces, const rwr_instance_raw *instances,
-                          uint32_t n_instances, const MaterialRec *materials, TriRecord *tris, ShadeRec *shade, CullRec *cull)
+                          uint32_t n_instances, const MaterialRec *materials, TriRecord *tris, ShadeRec *shade, CullRec *cull,
+                          TangentRec *tangents)
 {
     const uint32_t total = n_faces * (n_instances ? n_instances : 1u);
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(k_prebake, dim3((total + 255) / 256), dim3(256), 0, s, verts, faces, face_material, n_faces,
-                       instances, n_instances, materials, tris, shade, cull);
+                       instances, n_instances, materials, tris, shade, cull, tangents);
     return hipGetLastError();
 }
 

@@ -23,8 +23,10 @@ namespace rwr {
 #ifndef RWR_P2_OCC
 #define RWR_P2_OCC 7  // 72 VGPRs: the shading step needs 66; at 8 waves (64) it spills and is slower (measured)
 #endif
-template <bool AUX, bool CULL>
-__global__ void __launch_bounds__(256, AUX ? 4 : RWR_P2_OCC)
+// NMAP: normal-mapped shading (extension, RWR_FLAG_NORMAL_MAP) — its own instantiation, so that the reference's frame keeps
+// its registers.
+template <bool AUX, bool CULL, bool NMAP>
+__global__ void __launch_bounds__(256, (AUX || NMAP) ? 4 : RWR_P2_OCC)
 // (the first eleven arguments repeat FrameParams fields: they are what a wave needs first, and the Makefile
 // has their 14 dwords preloaded into SGPRs)
 k_primary_p2(const FrameTri *__restrict__ ftris, const float4 *__restrict__ ray_colp, const float4 *__restrict__ ray_row,
@@ -186,7 +188,8 @@ k_primary_p2(const FrameTri *__restrict__ ftris, const float4 *__restrict__ ray_
     }
     if (__any(any2(obj >= 0))) {  // wave-uniform; lanes without a mesh winner shade face 0 and drop the result
         f2 cr, cg, cb;
-        if (p.n_materials > 1u) shade_mesh_pair<true, false>(p, shade, tex, obj, last_shade, best, D, cr, cg, cb);
+        if (NMAP) shade_mesh_pair<true, false, true>(p, shade, tex, obj, last_shade, best, D, cr, cg, cb);   // (per-face material path)
+        else if (p.n_materials > 1u) shade_mesh_pair<true, false>(p, shade, tex, obj, last_shade, best, D, cr, cg, cb);
         else if (n_tested == 1u) shade_mesh_pair<false, true>(p, shade, tex, obj, last_shade, best, D, cr, cg, cb);
         else shade_mesh_pair<false, false>(p, shade, tex, obj, last_shade, best, D, cr, cg, cb);
         // rgba8unorm conversion of both pixels (rwr_device.h); alpha 2.0 -> 255
@@ -233,17 +236,28 @@ hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriReco
     const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
     // ev_start / ev_stop (may be null): timestamps of this dispatch itself (hipExtLaunchKernelGGL), i.e. the
     // kernel's own duration as a profiler reports it, without the gap to the preceding kernel
-    if (aux && do_cull) hipExtLaunchKernelGGL((k_primary_p2<true, true>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg);
-    else if (aux) hipExtLaunchKernelGGL((k_primary_p2<true, false>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg);
-    else if (do_cull) hipExtLaunchKernelGGL((k_primary_p2<false, true>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg);
-    else hipExtLaunchKernelGGL((k_primary_p2<false, false>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg);
+    const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0 && fp.tangents != nullptr;
+#define RWR_P2_LAUNCH(A, C, N) hipExtLaunchKernelGGL((k_primary_p2<A, C, N>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, \
+    fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg)
+    if (nmap) {
+        if (aux && do_cull) RWR_P2_LAUNCH(true, true, true);
+        else if (aux) RWR_P2_LAUNCH(true, false, true);
+        else if (do_cull) RWR_P2_LAUNCH(false, true, true);
+        else RWR_P2_LAUNCH(false, false, true);
+    } else {
+        if (aux && do_cull) RWR_P2_LAUNCH(true, true, false);
+        else if (aux) RWR_P2_LAUNCH(true, false, false);
+        else if (do_cull) RWR_P2_LAUNCH(false, true, false);
+        else RWR_P2_LAUNCH(false, false, false);
+    }
+#undef RWR_P2_LAUNCH
     return hipGetLastError();
 }
 
 hipError_t preload_kernels_primary_p2()
 {
     hipFuncAttributes attr;
-    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((&k_primary_p2<false, true>)));
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((&k_primary_p2<false, true, false>)));
 }
 
 }  // namespace rwr

@@ -266,7 +266,8 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
         f2 tr = splat(0.0f), tgc = splat(0.0f), tb = splat(0.0f);
         if (__any(any2(obj >= 0))) {
             f2 mr, mg, mb, xr, xg, xb;
-            if (p.n_materials > 1u) shade_mesh_pair<true, false>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
+            if (p.flags & RWR_FLAG_NORMAL_MAP) shade_mesh_pair<true, false, true>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
+            else if (p.n_materials > 1u) shade_mesh_pair<true, false>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
             else if (n_tested == 1u) shade_mesh_pair<false, true>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
             else shade_mesh_pair<false, false>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
             const i2 is_mesh = obj >= 0;

@@ -292,14 +292,46 @@ RWR_DEV f3 mesh_combine(f3 texel, float ndl, float sp, const float *ka, const fl
                __builtin_fmaf(ks[1], sp, __builtin_fmaf(texel.y, ndl, ka[1])),
                __builtin_fmaf(ks[2], sp, __builtin_fmaf(texel.z, ndl, ka[2])));
 }
+// Normal-mapped light terms (extension, RWR_FLAG_NORMAL_MAP; defined in oracle/rt_oracle.c normal_mapped): m = 2 c - 1 from
+// the filtered LINEAR texel c of the map, n' = normalize(t m.x + b m.y + s n m.z) with s = -1 when the flat normal was
+// flipped towards the ray (:140-142), n' = s n when the sum vanishes; n' replaces the flat normal in :226-229.
+RWR_DEV void mesh_light_terms_nm(const ShadeRec &S, const TangentRec &G, f3 c, float ndotd, const HalfVec &hv, float &ndl, float &hn)
+{
+    const float s = ndotd > 0.0f ? -1.0f : 1.0f;
+    const f3 m = mk3(2.0f * c.x - 1.0f, 2.0f * c.y - 1.0f, (2.0f * c.z - 1.0f) * s);
+    f3 n = mk3(__builtin_fmaf(G.t[0], m.x, __builtin_fmaf(G.b[0], m.y, S.n[0] * m.z)),
+               __builtin_fmaf(G.t[1], m.x, __builtin_fmaf(G.b[1], m.y, S.n[1] * m.z)),
+               __builtin_fmaf(G.t[2], m.x, __builtin_fmaf(G.b[2], m.y, S.n[2] * m.z)));
+    const float l2 = cdot(n, n);
+    if (!(l2 > 1e-20f)) n = mk3(S.n[0] * s, S.n[1] * s, S.n[2] * s);
+    else { const float r = __builtin_amdgcn_rsqf(l2); n = mk3(n.x * r, n.y * r, n.z * r); }
+    ndl = fmaxf(cdot(n, mesh_light_dir()), 0.0f);
+    hn = fmaxf(cdot(hv.h, n) * hv.rh, 0.0f);
+}
+// texel-space position in a part's normal map of the diffuse texel-space position `pos` (the maps may differ in size)
+RWR_DEV f2 nmap_texel_pos(const MaterialRec &M, f2 pos)
+{
+    const f2 scale = f2{(float)M.nmap_w / (float)M.tex_w, (float)M.nmap_h / (float)M.tex_h};
+    return fma2(pos + 0.5f, scale, splat(-0.5f));
+}
+
 struct Shaded { f3 colour, albedo; };  // local shading E and the surface's diffuse reflectance
+// G, Mn: the face's tangent frame and its material when the render asked for normal-mapped shading, else nullptr
 RWR_DEV Shaded shade_mesh(const ShadeRec &S, float eu, float ev, float ndotd, f3 D, const float *ka, const float *ks,
-                          const float4 *__restrict__ tex, uint32_t pitch, float wmax, float hmax)
+                          const float4 *__restrict__ tex, uint32_t pitch, float wmax, float hmax,
+                          const TangentRec *__restrict__ G = nullptr, const MaterialRec *__restrict__ Mn = nullptr)
 {
     float ndl, hn;
-    mesh_light_terms(S, ndotd, mesh_half_vector(D), ndl, hn);
+    const HalfVec hv = mesh_half_vector(D);
+    const f2 pos = mesh_texel_pos(S, eu, ev);
+    if (G && Mn && Mn->nmap) {
+        const f3 c = tex_sample_bilinear(Mn->nmap, Mn->nmap_w * 16u, (float)(Mn->nmap_w - 1u), (float)(Mn->nmap_h - 1u), nmap_texel_pos(*Mn, pos));
+        mesh_light_terms_nm(S, *G, c, ndotd, hv, ndl, hn);
+    } else {
+        mesh_light_terms(S, ndotd, hv, ndl, hn);
+    }
     Shaded r;
-    r.albedo = mesh_texel(S, eu, ev, tex, pitch, wmax, hmax);
+    r.albedo = tex_sample_bilinear(tex, pitch, wmax, hmax, pos);
     r.colour = mesh_combine(r.albedo, ndl, pow32(hn), ka, ks);
     return r;
 }

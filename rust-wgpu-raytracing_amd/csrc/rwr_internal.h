@@ -63,8 +63,19 @@ struct alignas(16) MaterialRec {
     float specular[3]; uint32_t tex_h;
     const float4 *tex;
     float wmax, hmax;               // (float)(tex_w - 1), (float)(tex_h - 1): the ClampToEdge bounds
+    const float4 *nmap;             // optional normal map (extension, RWR_FLAG_NORMAL_MAP): linear texels, nullptr = none
+    uint32_t nmap_w, nmap_h;
 };
-static_assert(sizeof(MaterialRec) == 48, "MaterialRec is 48 B");
+static_assert(sizeof(MaterialRec) == 64, "MaterialRec is 64 B");
+
+// Per-face tangent frame for normal-mapped shading (extension; 32 B, made by k_prebake in double and rounded once):
+// t = normalize(dP/du - n (n . dP/du)), b = +-cross(n, t) towards -dP/dv' (v' = 1 - v: the sampling space of
+// compute.wgsl:224; the map's green axis points up the image); zeros for degenerate texture coordinates.
+struct alignas(16) TangentRec {
+    float t[3]; float pad0;
+    float b[3]; float pad1;
+};
+static_assert(sizeof(TangentRec) == 32, "TangentRec is 32 B");
 
 // The three corners again, packed (48 B): what the conservative tile/block
 // frustum tests read, one record per lane, coalesced.
@@ -162,6 +173,7 @@ struct FrameParams {
     const MaterialRec *materials;
     uint32_t n_materials;
     uint32_t pad_m;
+    const TangentRec *tangents;   // per face (RWR_FLAG_NORMAL_MAP)
 };
 
 // context.cpp: records the calling thread's error message, returns `code`.
@@ -170,7 +182,8 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 // kernels_primary.hip
 hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, const rwr_model_face_small *faces,
                           const uint32_t *face_material, uint32_t n_faces, const rwr_instance_raw *instances,
-                          uint32_t n_instances, const MaterialRec *materials, TriRecord *tris, ShadeRec *shade, CullRec *cull);
+                          uint32_t n_instances, const MaterialRec *materials, TriRecord *tris, ShadeRec *shade, CullRec *cull,
+                          TangentRec *tangents);
 // Wavefront integrator state (kernels_wf_primary.hip / kernels_wf_bounce.hip).  A launch group traces `group`
 // samples of every pixel.  A *tile* is the 64x8-pixel block of one workgroup of the primary stage (4 waves of
 // 32x4 pixels, two pixels per lane); its *pool* is the bounce rays those samples emit.  Ray queue = SoA in HBM,

@@ -139,11 +139,14 @@ RWR_DEV Shaded shade_winner(const FrameParams &p, int32_t obj, float t, float u,
 {
     if (obj >= 0) {
         const ShadeRec &S = shade[obj];
+        // normal-mapped shading (extension): the face's tangent frame and its material's map
+        const TangentRec *G = (p.flags & RWR_FLAG_NORMAL_MAP) ? &p.tangents[obj] : nullptr;
+        const MaterialRec *Mn = G ? &p.materials[S.material] : nullptr;
         if (p.n_materials > 1u) {  // wave-uniform: per-face material (extension)
             const MaterialRec &M = p.materials[S.material];
-            return shade_mesh(S, u, v, ndotd, D, M.ambient, M.specular, M.tex, M.tex_w * 16u, M.wmax, M.hmax);
+            return shade_mesh(S, u, v, ndotd, D, M.ambient, M.specular, M.tex, M.tex_w * 16u, M.wmax, M.hmax, G, Mn);
         }
-        return shade_mesh(S, u, v, ndotd, D, p.ambient, p.specular, tex, p.tex_w * 16u, p.tex_wmax, p.tex_hmax);
+        return shade_mesh(S, u, v, ndotd, D, p.ambient, p.specular, tex, p.tex_w * 16u, p.tex_wmax, p.tex_hmax, G, Mn);
     }
     const uint32_t k = (uint32_t)(-2 - obj);
     const f3 P = along(O, t, D);

@@ -16,11 +16,13 @@ namespace rwr {
 // frame kernel spends as long on the latency chain of its first and last waves as on arithmetic.
 // (tr, tg, tb): the filtered diffuse texel of each pixel — the surface's albedo, which the wavefront integrator
 // carries along the bounce ray.
-template <bool MULTI, bool UNIFORM>
+// NMAP: normal-mapped light terms where the face's material has a map (extension, RWR_FLAG_NORMAL_MAP).
+template <bool MULTI, bool UNIFORM, bool NMAP = false>
 RWR_DEV void shade_mesh_pair(const FrameParams &p, const ShadeRec *__restrict__ shade, const float4 *__restrict__ tex,
                              i2 obj, const ShadeRec &uS, const MeshHit2 &best, v3 D, f2 &cr, f2 &cg, f2 &cb,
                              f2 &tr, f2 &tg, f2 &tb)
 {
+    static_assert(!(NMAP && UNIFORM), "the normal-mapped path fetches per-pixel records");
     const v3 h = sub3(splat3(mesh_light_dir()), D);          // :229, un-normalised
     const f2 hh = fma2(h.z, h.z, fma2(h.y, h.y, h.x * h.x));
     const f2 rh = f2{__builtin_amdgcn_rsqf(hh.x), __builtin_amdgcn_rsqf(hh.y)};
@@ -40,6 +42,14 @@ RWR_DEV void shade_mesh_pair(const FrameParams &p, const ShadeRec *__restrict__ 
         mesh_light_terms(S, k ? best.ndotd.y : best.ndotd.x, hv, a, c);
         if (k) { ndl.y = a; hn.y = c; } else { ndl.x = a; hn.x = c; }
         const f2 pos = mesh_texel_pos(S, k ? best.u.y : best.u.x, k ? best.v.y : best.v.x);
+        if (NMAP) {
+            const MaterialRec &Mn = p.materials[S.material];
+            if (Mn.nmap) {
+                const f3 cn = tex_sample_bilinear(Mn.nmap, Mn.nmap_w * 16u, (float)(Mn.nmap_w - 1u), (float)(Mn.nmap_h - 1u), nmap_texel_pos(Mn, pos));
+                mesh_light_terms_nm(S, p.tangents[(uint32_t)max(k ? obj.y : obj.x, 0)], cn, k ? best.ndotd.y : best.ndotd.x, hv, a, c);
+                if (k) { ndl.y = a; hn.y = c; } else { ndl.x = a; hn.x = c; }
+            }
+        }
         if (MULTI) {  // per-face material (extension)
             const MaterialRec &M = p.materials[S.material];
             taps[k] = tex_taps(M.tex_w * 16u, M.wmax, M.hmax, pos);
@@ -68,12 +78,12 @@ RWR_DEV void shade_mesh_pair(const FrameParams &p, const ShadeRec *__restrict__ 
     cb = fma2(ksb, sp, fma2(tb, ndl, kab));
 }
 
-template <bool MULTI, bool UNIFORM>
+template <bool MULTI, bool UNIFORM, bool NMAP = false>
 RWR_DEV void shade_mesh_pair(const FrameParams &p, const ShadeRec *__restrict__ shade, const float4 *__restrict__ tex,
                              i2 obj, const ShadeRec &uS, const MeshHit2 &best, v3 D, f2 &cr, f2 &cg, f2 &cb)
 {
     f2 tr, tg, tb;
-    shade_mesh_pair<MULTI, UNIFORM>(p, shade, tex, obj, uS, best, D, cr, cg, cb, tr, tg, tb);
+    shade_mesh_pair<MULTI, UNIFORM, NMAP>(p, shade, tex, obj, uS, best, D, cr, cg, cb, tr, tg, tb);
 }
 
 }  // namespace rwr

@@ -54,6 +54,8 @@ struct Material {
     texture::Texture diffuse_texture;
     std::string diffuse_texture_file;
     std::string normal_texture_file;  // map_Bump: parsed, not consumed by the reference shader (resources.rs:189)
+    texture::Texture normal_texture;  // extension: the decoded map_Bump image when the file is there (RWR_FLAG_NORMAL_MAP);
+                                      // empty otherwise — the reference never opens it, so its absence is not an error
     std::array<float, 3> ambient{0, 0, 0};
     std::array<float, 3> diffuse{0, 0, 0};
     std::array<float, 3> specular{0, 0, 0};

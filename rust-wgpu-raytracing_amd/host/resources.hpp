@@ -295,6 +295,10 @@ inline Error load_model_compute(const std::string &res_dir, const std::string &f
         if (m.diffuse_texture.empty()) return {RWR_ERR_IO, "material '" + m.name + "' has no map_Kd texture"};
         e = load_texture(res_dir, m.diffuse_texture, mat.diffuse_texture);  // resources.rs:189
         if (e) return e;
+        if (!m.normal_texture.empty()) {  // extension (normal-mapped shading); a missing or unreadable map is no error
+            texture::Texture nm;
+            if (!load_texture(res_dir, m.normal_texture, nm)) mat.normal_texture = std::move(nm);
+        }
         for (int k = 0; k < 3; k++) { mat.ambient[k] = m.ambient[k]; mat.diffuse[k] = m.diffuse[k]; mat.specular[k] = m.specular[k]; }
         mat.shininess = m.shininess;
         out.materials.push_back(std::move(mat));

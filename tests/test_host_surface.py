@@ -225,6 +225,17 @@ def test_decoders_under_address_sanitizer(rwr, tmp_path):
     assert r.stdout.count(": ok") >= 3 and "rejected" in r.stdout
 
 
+def test_loader_exposes_the_normal_map(rwr, ref_loader):
+    """map_Bump (cube.mtl:13) is parsed and decoded for the normal-mapped shading extension; suzanne names none."""
+    from PIL import Image
+    cube = rwr.load_model_compute("cube.obj")
+    want = np.asarray(Image.open(os.path.join(rwr.RES_DIR, "cube-normal.png")).convert("RGBA"), dtype=np.uint8)
+    assert cube["normal_map"] is not None and np.array_equal(cube["normal_map"], want)
+    assert np.array_equal(ref_loader.load_model_compute(rwr.RES_DIR, "cube.obj")["normal_map"], want)
+    assert rwr.load_model_compute("suzanne_lowpoly.obj")["normal_map"] is None
+    assert rwr.load_model_parts("cube.obj")[0]["normal_map"] is not None
+
+
 def test_loader_error_behaviour(rwr, tmp_path):
     with pytest.raises(rwr.RwrError) as ei:                          # anyhow::Error from fs::read_to_string
         rwr.load_model_compute("does_not_exist.obj")
