@@ -82,7 +82,7 @@ k_primary_dormant(const FrameParams p, const SingleTriangles st, const TriRecord
         const f3 c = shade_sphere(N, D);
         cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
     } else if (obj != -1) {
-        const f3 c = shade_winner(p, obj, win_t, best.u, best.v, best.ndotd, shade, tex, O, D).colour;
+        const f3 c = ((p.flags & RWR_FLAG_NORMAL_MAP) ? shade_winner<true>(p, obj, win_t, best.u, best.v, best.ndotd, shade, tex, O, D) : shade_winner<false>(p, obj, win_t, best.u, best.v, best.ndotd, shade, tex, O, D)).colour;
         cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
     }
     if (in_range) {

@@ -307,7 +307,7 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRe
     // final_color with alpha 1 + 1 (compute.wgsl:231-234).
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
     if (r.obj != -1) {
-        const f3 c = shade_winner(p, r.obj, r.t, r.mesh.u, r.mesh.v, r.mesh.ndotd, shade, tex, O, D).colour;
+        const f3 c = ((p.flags & RWR_FLAG_NORMAL_MAP) ? shade_winner<true>(p, r.obj, r.t, r.mesh.u, r.mesh.v, r.mesh.ndotd, shade, tex, O, D) : shade_winner<false>(p, r.obj, r.t, r.mesh.u, r.mesh.v, r.mesh.ndotd, shade, tex, O, D)).colour;
         cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
     }
 

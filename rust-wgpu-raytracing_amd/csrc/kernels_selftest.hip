@@ -88,9 +88,10 @@ k_measure_valu(ulonglong2 *out, uint32_t iters, float s)
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_sched_barrier(0);
     for (uint32_t i = 0; i < iters; i++) {
-        if (MODE == 0) {
-            a0 = __builtin_fmaf(a0, s, a0); a1 = __builtin_fmaf(a1, s, a1); a2 = __builtin_fmaf(a2, s, a2); a3 = __builtin_fmaf(a3, s, a3);
-            a4 = __builtin_fmaf(a4, s, a4); a5 = __builtin_fmaf(a5, s, a5); a6 = __builtin_fmaf(a6, s, a6); a7 = __builtin_fmaf(a7, s, a7);
+        if (MODE == 0) {   // (inline assembly: the compiler would pair adjacent scalar FMAs into v_pk_fma_f32)
+            asm volatile("v_fma_f32 %0, %0, %8, %0\n\tv_fma_f32 %1, %1, %8, %1\n\tv_fma_f32 %2, %2, %8, %2\n\tv_fma_f32 %3, %3, %8, %3\n\t"
+                         "v_fma_f32 %4, %4, %8, %4\n\tv_fma_f32 %5, %5, %8, %5\n\tv_fma_f32 %6, %6, %8, %6\n\tv_fma_f32 %7, %7, %8, %7"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s));
         } else {
             p0 = fma2(p0, sv, p0); p1 = fma2(p1, sv, p1); p2 = fma2(p2, sv, p2); p3 = fma2(p3, sv, p3);
             p4 = fma2(p4, sv, p4); p5 = fma2(p5, sv, p5); p6 = fma2(p6, sv, p6); p7 = fma2(p7, sv, p7);

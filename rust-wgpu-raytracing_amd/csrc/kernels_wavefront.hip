@@ -61,7 +61,7 @@ k_primary_bvh(const FrameParams p, const TriRecord *__restrict__ tris, const Sha
     }
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
     if (r.obj != -1) {
-        const f3 c = shade_winner(p, r.obj, r.t, r.mesh.u, r.mesh.v, r.mesh.ndotd, shade, tex, O, D).colour;
+        const f3 c = ((p.flags & RWR_FLAG_NORMAL_MAP) ? shade_winner<true>(p, r.obj, r.t, r.mesh.u, r.mesh.v, r.mesh.ndotd, shade, tex, O, D) : shade_winner<false>(p, r.obj, r.t, r.mesh.u, r.mesh.v, r.mesh.ndotd, shade, tex, O, D)).colour;
         cr = c.x; cg = c.y; cb = c.z; ca = 2.0f;
     }
     if (in_range) {

@@ -31,8 +31,8 @@
 #include <algorithm>
 
 #include "rwr_bvh.h"
-#include "rwr_device_p2.h"
 #include "rwr_primary.h"
+#include "rwr_shade_p2.h"
 
 namespace rwr {
 
@@ -279,7 +279,7 @@ RWR_DEV bool next_item(TraceShared &sh, const PoolInfo *__restrict__ info, uint3
 // ---------------------------------------------------------------------------------------------------------------
 // Pools that are sparse or spread out (silhouette tiles, distant instances): one ray per lane, per-lane BVH
 // traversal with the nodelets and the traversal stacks in LDS (rwr_bvh.h).
-template <bool NODES_IN_LDS>
+template <bool NODES_IN_LDS, bool NMAP>
 __global__ void __launch_bounds__(256)
 k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
                 const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf, const PoolInfo *__restrict__ info,
@@ -333,7 +333,7 @@ k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const S
                 if (mh.have && (!have || mh.t < best_t)) { have = true; best_t = mh.t; obj = (int32_t)mh.idx; }
             }
             if (have) {
-                const f3 e1 = shade_winner(p, obj, best_t, mh.u, mh.v, mh.ndotd, shade, tex, O, D).colour;
+                const f3 e1 = shade_winner<NMAP>(p, obj, best_t, mh.u, mh.v, mh.ndotd, shade, tex, O, D).colour;
                 add_contribution(sh, e, thr.x * e1.x, thr.y * e1.y, thr.z * e1.z);
             }
         }
@@ -438,8 +438,11 @@ RWR_DEV i2 sphere_pair_intersect_t(f3 center, float radius, v3 O, v3 D, f2 &t_ou
     return ~miss & (use1 | use2);
 }
 
-template <int DUMMY>
-__global__ void __launch_bounds__(256)
+#ifndef RWR_PACKET_OCC
+#define RWR_PACKET_OCC 4
+#endif
+template <bool NMAP>
+__global__ void __launch_bounds__(256, RWR_PACKET_OCC)
 k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
                   const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf, const PoolInfo *__restrict__ info,
                   uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list, uint32_t parity, uint32_t n_tiles)
@@ -588,16 +591,28 @@ k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const
 
         // -- shade the second hit, add albedo(h0) * E(h1) to the pixel's sums --------------------------------------
         if (__any(any2(have))) {
+            f2 er = splat(0.0f), eg = splat(0.0f), eb = splat(0.0f);
+            const i2 is_mesh = have & (obj >= 0);
+            if (__any(any2(is_mesh))) {   // mesh winners: both rays of a lane at once (packed arithmetic, rwr_shade_p2.h)
+                const ShadeRec none = {};
+                if (NMAP) shade_mesh_pair<true, false, true>(p, shade, tex, obj, none, best, R.D, er, eg, eb);
+                else if (p.n_materials > 1u) shade_mesh_pair<true, false>(p, shade, tex, obj, none, best, R.D, er, eg, eb);
+                else shade_mesh_pair<false, false>(p, shade, tex, obj, none, best, R.D, er, eg, eb);
+            }
+            if (__any(any2(have & (obj < -1)))) {   // sphere winners (rare): one ray at a time
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                if (k ? have.y : have.x) {
-                    const f3 Ok = lane3(R.O, k), Dk = lane3(R.D, k);
-                    const f3 ek = shade_winner(p, k ? obj.y : obj.x, k ? best_t.y : best_t.x, k ? best.u.y : best.u.x,
-                                               k ? best.v.y : best.v.x, k ? best.ndotd.y : best.ndotd.x, shade, tex, Ok, Dk).colour;
-                    add_contribution(sh, k ? e1 : e0, (k ? thr.x.y : thr.x.x) * ek.x, (k ? thr.y.y : thr.y.x) * ek.y,
-                                     (k ? thr.z.y : thr.z.x) * ek.z);
+                for (int k = 0; k < 2; k++) {
+                    const int o = k ? obj.y : obj.x;
+                    if ((k ? have.y : have.x) && o < -1) {
+                        const f3 Ok = lane3(R.O, k), Dk = lane3(R.D, k);
+                        const f3 ek = shade_winner<false>(p, o, k ? best_t.y : best_t.x, 0.0f, 0.0f, 0.0f, shade, tex, Ok, Dk).colour;
+                        if (k) { er.y = ek.x; eg.y = ek.y; eb.y = ek.z; } else { er.x = ek.x; eg.x = ek.y; eb.x = ek.z; }
+                    }
                 }
             }
+            const f2 cr = thr.x * er, cg = thr.y * eg, cb = thr.z * eb;
+            if (have.x) add_contribution(sh, e0, cr.x, cg.x, cb.x);
+            if (have.y) add_contribution(sh, e1, cr.y, cg.y, cb.y);
         }
     }
     __syncthreads();
@@ -617,15 +632,21 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
     hipLaunchKernelGGL(k_wf_sort, dim3(n_tiles), dim3(256), (size_t)sample_count * kWfTilePixels * sizeof(uint16_t), s, wf, info, counters, pool_list, n_tiles, parity, sample_count,
                        packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);
     const dim3 grid(std::min(kWfTraceGroups, n_tiles * kWfMaxSplit));
-    if (packets)
-        hipLaunchKernelGGL((k_wf_trace_packet<0>), grid, dim3(256), 0, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles);
+    const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0;
+    if (packets) {
+        if (nmap) hipLaunchKernelGGL((k_wf_trace_packet<true>), grid, dim3(256), 0, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles);
+        else hipLaunchKernelGGL((k_wf_trace_packet<false>), grid, dim3(256), 0, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles);
+    }
     const size_t fixed = (size_t)bvh.stack_depth * 256u * 4u;
     const size_t node_bytes = (size_t)bvh.n_nodes * sizeof(BvhNode4);
     // nodelets go to LDS when the workgroup then still fits a CU at least four times (160 KiB LDS, 12 KiB static)
-    if (node_bytes + fixed <= 28u * 1024u)
-        hipLaunchKernelGGL((k_wf_trace_lane<true>), grid, dim3(256), node_bytes + fixed, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles);
-    else
-        hipLaunchKernelGGL((k_wf_trace_lane<false>), grid, dim3(256), fixed, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles);
+#define RWR_LANE_LAUNCH(L, N, BYTES) hipLaunchKernelGGL((k_wf_trace_lane<L, N>), grid, dim3(256), BYTES, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles)
+    if (node_bytes + fixed <= 28u * 1024u) {
+        if (nmap) RWR_LANE_LAUNCH(true, true, node_bytes + fixed); else RWR_LANE_LAUNCH(true, false, node_bytes + fixed);
+    } else {
+        if (nmap) RWR_LANE_LAUNCH(false, true, fixed); else RWR_LANE_LAUNCH(false, false, fixed);
+    }
+#undef RWR_LANE_LAUNCH
     return hipGetLastError();
 }
 
@@ -634,7 +655,7 @@ size_t wf_pool_info_bytes() { return sizeof(PoolInfo); }
 hipError_t preload_kernels_wf_bounce()
 {
     hipFuncAttributes attr;
-    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((&k_wf_trace_packet<0>)));
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((&k_wf_trace_packet<false>)));
 }
 
 }  // namespace rwr

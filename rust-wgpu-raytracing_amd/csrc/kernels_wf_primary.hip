@@ -123,8 +123,8 @@ RWR_DEV v3 bounce_direction_pair(v3 n, u2 base, i2 want)
 #ifndef RWR_WF_OCC
 #define RWR_WF_OCC 4
 #endif
-template <bool AUX, bool CULL>
-__global__ void __launch_bounds__(256, AUX ? 3 : RWR_WF_OCC)
+template <bool AUX, bool CULL, bool NMAP>
+__global__ void __launch_bounds__(256, (AUX || NMAP) ? 3 : RWR_WF_OCC)
 k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_begin, uint32_t bins_enabled,
              int32_t mesh_x0, int32_t mesh_y0, int32_t mesh_x1, int32_t mesh_y1, uint32_t sample_begin, uint32_t sample_count,
              const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
@@ -266,7 +266,7 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
         f2 tr = splat(0.0f), tgc = splat(0.0f), tb = splat(0.0f);
         if (__any(any2(obj >= 0))) {
             f2 mr, mg, mb, xr, xg, xb;
-            if (p.flags & RWR_FLAG_NORMAL_MAP) shade_mesh_pair<true, false, true>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
+            if (NMAP) shade_mesh_pair<true, false, true>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
             else if (p.n_materials > 1u) shade_mesh_pair<true, false>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
             else if (n_tested == 1u) shade_mesh_pair<false, true>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
             else shade_mesh_pair<false, false>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
@@ -370,10 +370,20 @@ hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriReco
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0, do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
 #define RWR_WF_ARGS ftris, fp.n_tris, fp.row_begin, fp.bins.enabled, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], \
                     sample_begin, sample_count, fp, tris, shade, tex, tg, wf
-    if (aux && do_cull) hipLaunchKernelGGL((k_wf_primary<true, true>), grid, block, 0, s, RWR_WF_ARGS);
-    else if (aux) hipLaunchKernelGGL((k_wf_primary<true, false>), grid, block, 0, s, RWR_WF_ARGS);
-    else if (do_cull) hipLaunchKernelGGL((k_wf_primary<false, true>), grid, block, 0, s, RWR_WF_ARGS);
-    else hipLaunchKernelGGL((k_wf_primary<false, false>), grid, block, 0, s, RWR_WF_ARGS);
+    const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0;
+#define RWR_WF_LAUNCH(A, C, N) hipLaunchKernelGGL((k_wf_primary<A, C, N>), grid, block, 0, s, RWR_WF_ARGS)
+    if (nmap) {
+        if (aux && do_cull) RWR_WF_LAUNCH(true, true, true);
+        else if (aux) RWR_WF_LAUNCH(true, false, true);
+        else if (do_cull) RWR_WF_LAUNCH(false, true, true);
+        else RWR_WF_LAUNCH(false, false, true);
+    } else {
+        if (aux && do_cull) RWR_WF_LAUNCH(true, true, false);
+        else if (aux) RWR_WF_LAUNCH(true, false, false);
+        else if (do_cull) RWR_WF_LAUNCH(false, true, false);
+        else RWR_WF_LAUNCH(false, false, false);
+    }
+#undef RWR_WF_LAUNCH
 #undef RWR_WF_ARGS
     return hipGetLastError();
 }
@@ -381,7 +391,7 @@ hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriReco
 hipError_t preload_kernels_wf_primary()
 {
     hipFuncAttributes attr;
-    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((&k_wf_primary<false, true>)));
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((&k_wf_primary<false, true, false>)));
 }
 
 }  // namespace rwr

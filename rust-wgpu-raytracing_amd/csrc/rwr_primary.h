@@ -134,14 +134,17 @@ RWR_DEV void primary_visibility(const FrameParams &p, const TriRecord *__restric
 // Local shading E of the winning surface (colour path) -> rgb (alpha is 2.0 on a hit), and its albedo.
 // (obj, t: the winner and its distance; u, v, ndotd: MeshHit fields of a mesh winner — by value, a
 // reference to the hit record keeps part of it in memory.)
+// NMAP: the render asked for normal-mapped shading (RWR_FLAG_NORMAL_MAP) — a template parameter so that kernels which
+// are instantiated without it keep their registers.
+template <bool NMAP = false>
 RWR_DEV Shaded shade_winner(const FrameParams &p, int32_t obj, float t, float u, float v, float ndotd,
                             const ShadeRec *__restrict__ shade, const float4 *__restrict__ tex, f3 O, f3 D)
 {
     if (obj >= 0) {
         const ShadeRec &S = shade[obj];
         // normal-mapped shading (extension): the face's tangent frame and its material's map
-        const TangentRec *G = (p.flags & RWR_FLAG_NORMAL_MAP) ? &p.tangents[obj] : nullptr;
-        const MaterialRec *Mn = G ? &p.materials[S.material] : nullptr;
+        const TangentRec *G = NMAP ? &p.tangents[obj] : nullptr;
+        const MaterialRec *Mn = NMAP ? &p.materials[S.material] : nullptr;
         if (p.n_materials > 1u) {  // wave-uniform: per-face material (extension)
             const MaterialRec &M = p.materials[S.material];
             return shade_mesh(S, u, v, ndotd, D, M.ambient, M.specular, M.tex, M.tex_w * 16u, M.wmax, M.hmax, G, Mn);
