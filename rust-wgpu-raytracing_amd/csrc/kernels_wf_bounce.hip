@@ -90,6 +90,7 @@ struct SortShared {
     uint32_t hist[kWfDirBins];
     uint32_t offs[kWfDirBins];
     uint32_t lo[3], hi[3];   // bounds of the ray origins of the group's first samples (order-preserving keys)
+    uint32_t wave_sum[4];
     uint32_t total;
 };
 
@@ -105,7 +106,7 @@ k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict_
 {
     __shared__ SortShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    uint16_t *s_bins = reinterpret_cast<uint16_t *>(s_dyn);   // direction bin of every slot (0xffff: no ray); 2 B x sample_count x 512
+    uint16_t *s_bins = reinterpret_cast<uint16_t *>(s_dyn);   // direction bin of every slot (0xffff: no ray), then the sorted list: 2 x 2 B x sample_count x 512
     const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t n_masks = sample_count * 8u, n_slots = sample_count * kWfTilePixels;
     if (tile == 0u && tid < (uint32_t)kCountersPerParity) counters[(parity ^ 1u) * kCountersPerParity + tid] = 0u;   // the next launch group's
@@ -182,11 +183,22 @@ k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict_
         }
     }
     __syncthreads();
-    for (uint32_t b = tid; b < kWfDirBins; b += 256u) {  // exclusive prefix (512 bins: two per thread, broadcast reads)
-        uint32_t sum = 0;
-        for (uint32_t j = 0; j < b; j++) sum += sh.hist[j];
-        sh.offs[b] = sum;
-        if ((b & 63u) == 0u) info[tile].oct_begin[b >> 6] = sum;
+    {   // exclusive prefix over the 512 bins: two bins per thread, shuffle scan inside a wave, four wave totals through LDS
+        static_assert(kWfDirBins == 512u, "two bins per thread of a 256-thread workgroup");
+        const uint32_t c0 = sh.hist[2u * tid], c1 = sh.hist[2u * tid + 1u];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if ((int)(tid & 63u) >= d) incl += up;
+        }
+        if ((tid & 63u) == 63u) sh.wave_sum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t before = incl - (c0 + c1);
+        for (uint32_t w = 0; w < (tid >> 6); w++) before += sh.wave_sum[w];
+        sh.offs[2u * tid] = before;
+        sh.offs[2u * tid + 1u] = before + c0;
+        if ((tid & 31u) == 0u) info[tile].oct_begin[tid >> 5] = before;   // bin 64 o = 2 * (32 o): where octant o begins
     }
     if (tid == 0u) {
         info[tile].oct_begin[8] = n_rays;
@@ -201,11 +213,17 @@ k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict_
         }
     }
     __syncthreads();
-    uint16_t *__restrict__ sorted = wf.sorted + pool_base;
+    // scatter inside LDS (64 two-byte stores to 64 different places would cost the memory pipe a cycle each), then the
+    // sorted list goes out in whole 16-byte pieces
+    uint16_t *s_sorted = s_bins + n_slots;
     for (uint32_t e = tid; e < n_slots; e += 256u) {
         const uint32_t bin = s_bins[e];
-        if (bin != 0xffffu) sorted[atomicAdd(&sh.offs[bin], 1u)] = (uint16_t)e;
+        if (bin != 0xffffu) s_sorted[atomicAdd(&sh.offs[bin], 1u)] = (uint16_t)e;
     }
+    __syncthreads();
+    uint4 *__restrict__ out = reinterpret_cast<uint4 *>(wf.sorted + pool_base);   // pool_base is a multiple of 512
+    const uint4 *src = reinterpret_cast<const uint4 *>(s_sorted);
+    for (uint32_t i = tid; i < (n_rays + 7u) / 8u; i += 256u) out[i] = src[i];
 }
 
 // What a trace workgroup keeps in LDS: fixed-point sums of albedo * E(h1) per pixel of the tile.
@@ -629,7 +647,7 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
     PoolInfo *info = static_cast<PoolInfo *>(pool_info);
     // well-filled, compact pools: packet traversal (its one stack is a VGPR of 64 entries)
     const bool packets = bvh.stack_depth <= 64u && packet_min_rays <= sample_count * kWfTilePixels && bvh.packet_extent > 0.0f;
-    hipLaunchKernelGGL(k_wf_sort, dim3(n_tiles), dim3(256), (size_t)sample_count * kWfTilePixels * sizeof(uint16_t), s, wf, info, counters, pool_list, n_tiles, parity, sample_count,
+    hipLaunchKernelGGL(k_wf_sort, dim3(n_tiles), dim3(256), 2u * (size_t)sample_count * kWfTilePixels * sizeof(uint16_t), s, wf, info, counters, pool_list, n_tiles, parity, sample_count,
                        packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);
     const dim3 grid(std::min(kWfTraceGroups, n_tiles * kWfMaxSplit));
     const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0;
