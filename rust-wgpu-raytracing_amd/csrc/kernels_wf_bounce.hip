@@ -546,9 +546,11 @@ k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const
                         const f2 y0 = fma2(splat(neary[i]), R.iy, R.oy), y1 = fma2(splat(fary[i]), R.iy, R.oy);
                         const f2 z0 = fma2(splat(nearz[i]), R.iz, R.oz), z1 = fma2(splat(farz[i]), R.iz, R.oz);
                         const f2 tnear = max2(max2(x0, y0), z0), tfar = min2(min2(x1, y1), z1);
-                        // conservative, exactly as rwr_bvh.h bvh_inner_step: relative slack on both distances, <=
-                        const f2 lo = max2(tnear - 4e-5f * abs2(tnear), splat(0.0f));
-                        const f2 hi = min2(tfar + 4e-5f * abs2(tfar) + 1e-30f, tb);
+                        // conservative like rwr_bvh.h bvh_inner_step (relative slack on both distances, <=), in fewer
+                        // instructions: entry distances below 0 clamp to 0 whatever their slack, and a box whose exit
+                        // distance is negative lies behind the ray with or without slack — so the slack is a scale
+                        const f2 lo = max2(tnear * 0.99996f, splat(0.0f));
+                        const f2 hi = min2(fma2(tfar, splat(1.00004f), splat(1e-30f)), tb);
                         const i2 in = lo <= hi;
                         const unsigned long long m = __ballot(any2(in));
                         if (m) {   // uniform: some ray of the packet can reach this child
