@@ -127,8 +127,7 @@ struct rwr_context {
     float aabb_lo[3] = {0, 0, 0}, aabb_hi[3] = {0, 0, 0};   // of the (flattened) world-space faces
     float auto_bvh_face_px = 150.0f;   // tunable: RWR_AUTO_BVH_FACE_PX (0 = never pick the BVH kernel by itself)
     // wavefront integrator state
-    DeviceBuffer<float4> d_accum, d_q0, d_q1;
-    DeviceBuffer<float> d_q2;
+    DeviceBuffer<float4> d_accum, d_rays;
     DeviceBuffer<unsigned long long> d_wf_masks;
     DeviceBuffer<uint16_t> d_wf_sorted;
     DeviceBuffer<uint32_t> d_wave_total;
@@ -514,7 +513,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
     ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release(); ctx->d_tangent.release();
     for (auto &t : ctx->d_nmaps) t.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
-    ctx->d_accum.release(); ctx->d_q0.release(); ctx->d_q1.release(); ctx->d_q2.release(); ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wave_total.release(); ctx->d_wf_fix.release(); ctx->d_pool_info.release(); ctx->d_wf_live.release(); ctx->d_pool_list.release(); for (auto &t : ctx->d_texs) t.release();
+    ctx->d_accum.release(); ctx->d_rays.release(); ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wave_total.release(); ctx->d_wf_fix.release(); ctx->d_pool_info.release(); ctx->d_wf_live.release(); ctx->d_pool_list.release(); for (auto &t : ctx->d_texs) t.release();
     ctx->d_face_mat.release(); ctx->d_materials.release();
     for (FrameSlot &sl : ctx->slots) {
         sl.release_buffers();
@@ -951,9 +950,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         RWR_HIP_CHECK(ctx->d_wave_total.ensure((size_t)n_tiles * 4u));
         if (rp.max_bounces) {
             const size_t slots = (size_t)n_tiles * group * kWfTilePixels;
-            RWR_HIP_CHECK(ctx->d_q0.ensure(slots));
-            RWR_HIP_CHECK(ctx->d_q1.ensure(slots));
-            RWR_HIP_CHECK(ctx->d_q2.ensure(slots));
+            RWR_HIP_CHECK(ctx->d_rays.ensure(2u * slots));
             RWR_HIP_CHECK(ctx->d_wf_sorted.ensure(slots));
             RWR_HIP_CHECK(ctx->d_wf_masks.ensure((size_t)n_tiles * group * 8u));
             RWR_HIP_CHECK(ctx->d_wf_fix.ensure(3u * n));
@@ -964,7 +961,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
                 RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wf_live.ptr, 0, 8 * sizeof(uint32_t), stream));
             }
         }
-        const WfBuffers wf{ctx->d_accum.ptr, ctx->d_wf_fix.ptr, ctx->d_q0.ptr, ctx->d_q1.ptr, ctx->d_q2.ptr, ctx->d_wf_masks.ptr, ctx->d_wf_sorted.ptr,
+        const WfBuffers wf{ctx->d_accum.ptr, ctx->d_wf_fix.ptr, ctx->d_rays.ptr, ctx->d_wf_masks.ptr, ctx->d_wf_sorted.ptr,
                            ctx->d_wave_total.ptr, group, tiles_x, ctx->d_wf_dbg.ptr};
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u,
                             ctx->wf_packet_extent * ctx->bvh_leaf_extent, ctx->wf_min_packet_pools};

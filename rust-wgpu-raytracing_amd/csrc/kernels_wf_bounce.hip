@@ -135,7 +135,7 @@ k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict_
             const uint32_t e = tid + 256u * (uint32_t)u;
             live_slot[u] = e < n_slots && ((sh.masks[e >> 6] >> (e & 63u)) & 1ull);
             o[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (live_slot[u]) o[u] = wf.q0[pool_base + e];
+            if (live_slot[u]) o[u] = wf.rays[2u * (pool_base + e)];
         }
         uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
 #pragma unroll
@@ -170,7 +170,7 @@ k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict_
             const uint32_t e = e0 + 256u * (uint32_t)u;
             live_slot[u] = e < n_slots && ((sh.masks[e >> 6] >> (e & 63u)) & 1ull);
             d[u] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-            if (live_slot[u]) d[u] = wf.q1[pool_base + e];
+            if (live_slot[u]) d[u] = wf.rays[2u * (pool_base + e) + 1u];
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -328,10 +328,9 @@ k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const S
         const uint16_t *__restrict__ sorted = wf.sorted + pool_base;
         for (uint32_t i = share * 256u + tid; i < n_rays; i += 256u * n_shares) {   // chunks of 256 sorted rays, dealt round-robin
             const uint32_t e = sorted[i];
-            const float4 a = wf.q0[pool_base + e], b = wf.q1[pool_base + e];
-            const float c = wf.q2[pool_base + e];
+            const float4 a = wf.rays[2u * (pool_base + e)], b = wf.rays[2u * (pool_base + e) + 1u];   // one 32-byte record
             const f3 O = mk3(a.x, a.y, a.z), D = mk3(b.x, b.y, b.z);
-            const f3 thr = mk3(a.w, b.w, c);
+            const f3 thr = mk3(wf_unorm16_lo(a.w), wf_unorm16_hi(a.w), wf_unorm16_lo(b.w));
 
             // nearest over spheres (in order), then the mesh; strict '<' keeps the earlier candidate on ties
             bool have = false;
@@ -506,11 +505,12 @@ k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const
         PairRays R;
         R.valid = i2{i0 < last ? -1 : 0, i1 < last ? -1 : 0};
         const uint32_t e0 = R.valid.x ? sorted[i0] : sorted[first], e1 = R.valid.y ? sorted[i1] : sorted[first];
-        const float4 a0 = wf.q0[pool_base + e0], b0 = wf.q1[pool_base + e0], a1 = wf.q0[pool_base + e1], b1 = wf.q1[pool_base + e1];
-        const float c0 = wf.q2[pool_base + e0], c1 = wf.q2[pool_base + e1];
+        const float4 a0 = wf.rays[2u * (pool_base + e0)], b0 = wf.rays[2u * (pool_base + e0) + 1u];   // one 32-byte record per ray
+        const float4 a1 = wf.rays[2u * (pool_base + e1)], b1 = wf.rays[2u * (pool_base + e1) + 1u];
         R.O = v3{f2{a0.x, a1.x}, f2{a0.y, a1.y}, f2{a0.z, a1.z}};
         R.D = v3{f2{b0.x, b1.x}, f2{b0.y, b1.y}, f2{b0.z, b1.z}};
-        const v3 thr = v3{f2{a0.w, a1.w}, f2{b0.w, b1.w}, f2{c0, c1}};
+        const v3 thr = v3{f2{wf_unorm16_lo(a0.w), wf_unorm16_lo(a1.w)}, f2{wf_unorm16_hi(a0.w), wf_unorm16_hi(a1.w)},
+                          f2{wf_unorm16_lo(b0.w), wf_unorm16_lo(b1.w)}};
         // slab constants by v_rcp_f32 (1 ulp): the box test is conservative by 4e-5 relative on either side
         R.ix = f2{__builtin_amdgcn_rcpf(R.D.x.x), __builtin_amdgcn_rcpf(R.D.x.y)};
         R.iy = f2{__builtin_amdgcn_rcpf(R.D.y.x), __builtin_amdgcn_rcpf(R.D.y.y)};

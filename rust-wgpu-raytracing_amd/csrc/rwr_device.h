@@ -437,4 +437,14 @@ RWR_DEV f3 bounce_direction(f3 n, uint32_t pixel, uint32_t sample, uint32_t seed
     return normalize3(d);
 }
 
+// Wavefront ray records (rwr_internal.h WfBuffers::rays): the throughput's three channels as unorm16 in the two w components.
+RWR_DEV float wf_pack_unorm16x2(float a, float b)
+{
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 pk = __builtin_amdgcn_cvt_pknorm_u16(a, b);   // v_cvt_pknorm_u16_f32: clamps to [0, 1], rounds to nearest
+    return __uint_as_float((uint32_t)pk.x | ((uint32_t)pk.y << 16));
+}
+RWR_DEV float wf_unorm16_lo(float w) { return (float)(__float_as_uint(w) & 0xffffu) * (1.0f / 65535.0f); }
+RWR_DEV float wf_unorm16_hi(float w) { return (float)(__float_as_uint(w) >> 16) * (1.0f / 65535.0f); }
+
 }  // namespace rwr

@@ -187,9 +187,12 @@ hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, co
 // Wavefront integrator state (kernels_wf_primary.hip / kernels_wf_bounce.hip).  A launch group traces `group`
 // samples of every pixel.  A *tile* is the 64x8-pixel block of one workgroup of the primary stage (4 waves of
 // 32x4 pixels, two pixels per lane); its *pool* is the bounce rays those samples emit.  Ray queue = SoA in HBM,
-// 36 B per bounce ray, at FIXED slots
+// 32 B per bounce ray, at FIXED slots
 //     slot = (tile * group + sample_in_group) * 512 + wave * 128 + k * 64 + lane        (k: which pixel of the lane)
-// q0 = {O.xyz, thr.r}, q1 = {D.xyz, thr.g}, q2 = thr.b; masks[(tile * group + s) * 8 + wave * 2 + k] = ballot of the
+// rays[2 slot] = {O.xyz, throughput r | g << 16}, rays[2 slot + 1] = {D.xyz, throughput b}: ONE 32-byte record per ray, because
+// the bounce stage reads rays in sorted order, i.e. at random slots, and every separate access costs a whole memory
+// sector (three separate arrays measured 4.5x the bytes the rays have); the throughput (the first hit's albedo, in
+// [0, 1]) travels as unorm16, which moves a colour by at most 8e-6 of the second hit's radiance.  masks[(tile * group + s) * 8 + wave * 2 + k] = ballot of the
 // lanes that emitted.  The bounce stage compacts a pool by those ballots while sorting it by direction.
 constexpr uint32_t kWfTileW = 64, kWfTileH = 8, kWfTilePixels = kWfTileW * kWfTileH;
 constexpr uint32_t kWfMaxGroup = 32;          // samples per launch group (LDS of the bounce stage is sized for it)
@@ -197,8 +200,7 @@ constexpr uint32_t kWfDirBins = 512;          // 8 octants x 8x8 cells of the oc
 struct WfBuffers {
     float4 *accum;                 // W*H RGBA32F running sums of the first hits' E(h0) (a = 2 * primary hits)
     unsigned long long *fix;       // 3 planes of W*H: fixed-point (2^-26) sums of albedo(h0) * E(h1), red, green, blue
-    float4 *q0, *q1;
-    float *q2;
+    float4 *rays;                  // two float4 per slot: {O.xyz, thr.r | thr.g << 16}, {D.xyz, thr.b} (throughput as unorm16)
     unsigned long long *masks;
     uint16_t *sorted;              // per tile: group * 512 pool slots in direction order (scratch of the bounce stage)
     uint32_t *wave_total;          // per tile and wave: bounce rays emitted over all groups of the frame

@@ -1,0 +1,66 @@
+"""Copies the round's evidence from gpurun_out/profile_r02/ (tools/profile_round2.sh) into profiles/ and derives
+profiles/r02_counters.json — the per-step counter sums bench.py puts into its roofline block."""
+import csv, glob, json, os, re, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "profile_r02")
+DST = os.path.join(ROOT, "profiles")
+for f in glob.glob(os.path.join(SRC, "bench_*.json")):
+    shutil.copy(f, os.path.join(DST, "r02_" + os.path.basename(f)))
+for f in glob.glob(os.path.join(SRC, "kernel_stats_*.csv")):
+    shutil.copy(f, os.path.join(DST, "r02_" + os.path.basename(f)))
+
+
+def pmc(cfg):
+    """kernel -> {counter: (mean per launch, launches seen)}"""
+    out = {}
+    cur = None
+    for line in open(os.path.join(SRC, f"pmc_{cfg}", "summary.txt")):
+        if not line.startswith(" "):
+            cur = line.strip().split("(")[0]
+            out[cur] = {}
+        else:
+            m = re.match(r"\s+(\S+)\s+mean\s+([\d.]+)\s+n=(\d+)", line)
+            if m:
+                out[cur][m.group(1)] = (float(m.group(2)), int(m.group(3)))
+    shutil.copy(os.path.join(SRC, f"pmc_{cfg}", "summary.txt"), os.path.join(DST, f"r02_pmc_{cfg}_summary.txt"))
+    return out
+
+
+def per_frame(cfg, frames_of_stats_run):
+    calls = {}
+    for r in csv.DictReader(open(os.path.join(SRC, f"kernel_stats_{cfg}.csv"))):
+        calls[r["Name"].split("(")[0]] = int(r["Calls"]) / frames_of_stats_run
+    return calls
+
+
+counters = {"_note": "per-step (= per-frame) sums over the kernels of one frame, from rocprofv3 --kernel-trace --pmc passes (tools/pmc2.sh, "
+                     "one counter group per run; per-launch means x launches per frame); FETCH_SIZE doubled on gfx950 (64 B counted per "
+                     "128-B read request), WRITE_SIZE taken as reported (MI355X_MICROARCH.md HBM section); KB -> bytes x 1024"}
+FRAMES = {"cfg2": None, "cfg3": 7, "cfg4": 11}   # frames the kernel-stats runs rendered (warm-up + timed + probe segments)
+for cfg in ("cfg2", "cfg3", "cfg4"):
+    p = pmc(cfg)
+    kernels = [k for k in p if any(t in k for t in ("k_primary_p2", "k_wf_", "k_bin_", "k_frame_setup"))]
+    if cfg == "cfg2":
+        per = {k: 1.0 for k in kernels}
+    else:
+        per = per_frame(cfg, FRAMES[cfg])
+    tot = {"SQ_ACTIVE_INST_VALU": 0.0, "SQ_INSTS_VALU": 0.0, "FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0}
+    detail = {}
+    for k in kernels:
+        n = per.get(k, 0.0)
+        c = p[k]
+        d = {"launches_per_frame": round(n, 3)}
+        for name, key in (("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU"), ("SQ_INSTS_VALU", "SQ_INSTS_VALU"), ("FETCH_SIZE", "FETCH_SIZE_KB"),
+                          ("WRITE_SIZE", "WRITE_SIZE_KB")):
+            if name in c:
+                d[key] = c[name][0]
+                tot[key] += c[name][0] * n
+        detail[k] = d
+    traffic = int((2.0 * tot["FETCH_SIZE_KB"] + tot["WRITE_SIZE_KB"]) * 1024)
+    counters[cfg] = {"source": f"profiles/r02_pmc_{cfg}_summary.txt", **{k: round(v, 1) for k, v in tot.items()},
+                     "traffic_bytes_per_step": traffic, "kernels": detail}
+json.dump(counters, open(os.path.join(DST, "r02_counters.json"), "w"), indent=1)
+for cfg in ("cfg2", "cfg3", "cfg4"):
+    c = counters[cfg]
+    print(cfg, {k: v for k, v in c.items() if k != "kernels"})
