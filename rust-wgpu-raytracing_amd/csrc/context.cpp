@@ -129,7 +129,7 @@ struct rwr_context {
     // wavefront integrator state
     DeviceBuffer<float4> d_accum, d_rays;
     DeviceBuffer<unsigned long long> d_wf_masks;
-    DeviceBuffer<uint16_t> d_wf_sorted;
+    DeviceBuffer<uint16_t> d_wf_sorted, d_wf_bins;
     DeviceBuffer<uint32_t> d_wave_total;
     DeviceBuffer<unsigned long long> d_wf_fix;   // fixed-point bounce sums, 3 planes
     DeviceBuffer<uint8_t> d_pool_info;
@@ -513,7 +513,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
     ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release(); ctx->d_tangent.release();
     for (auto &t : ctx->d_nmaps) t.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
-    ctx->d_accum.release(); ctx->d_rays.release(); ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wave_total.release(); ctx->d_wf_fix.release(); ctx->d_pool_info.release(); ctx->d_wf_live.release(); ctx->d_pool_list.release(); for (auto &t : ctx->d_texs) t.release();
+    ctx->d_accum.release(); ctx->d_rays.release(); ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wf_bins.release(); ctx->d_wave_total.release(); ctx->d_wf_fix.release(); ctx->d_pool_info.release(); ctx->d_wf_live.release(); ctx->d_pool_list.release(); for (auto &t : ctx->d_texs) t.release();
     ctx->d_face_mat.release(); ctx->d_materials.release();
     for (FrameSlot &sl : ctx->slots) {
         sl.release_buffers();
@@ -952,6 +952,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
             const size_t slots = (size_t)n_tiles * group * kWfTilePixels;
             RWR_HIP_CHECK(ctx->d_rays.ensure(2u * slots));
             RWR_HIP_CHECK(ctx->d_wf_sorted.ensure(slots));
+            RWR_HIP_CHECK(ctx->d_wf_bins.ensure(slots));
             RWR_HIP_CHECK(ctx->d_wf_masks.ensure((size_t)n_tiles * group * 8u));
             RWR_HIP_CHECK(ctx->d_wf_fix.ensure(3u * n));
             RWR_HIP_CHECK(ctx->d_pool_info.ensure((size_t)n_tiles * wf_pool_info_bytes()));
@@ -961,7 +962,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
                 RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wf_live.ptr, 0, 8 * sizeof(uint32_t), stream));
             }
         }
-        const WfBuffers wf{ctx->d_accum.ptr, ctx->d_wf_fix.ptr, ctx->d_rays.ptr, ctx->d_wf_masks.ptr, ctx->d_wf_sorted.ptr,
+        const WfBuffers wf{ctx->d_accum.ptr, ctx->d_wf_fix.ptr, ctx->d_rays.ptr, ctx->d_wf_masks.ptr, ctx->d_wf_bins.ptr, ctx->d_wf_sorted.ptr,
                            ctx->d_wave_total.ptr, group, tiles_x, ctx->d_wf_dbg.ptr};
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u,
                             ctx->wf_packet_extent * ctx->bvh_leaf_extent, ctx->wf_min_packet_pools};

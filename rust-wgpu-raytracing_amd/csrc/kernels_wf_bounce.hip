@@ -38,19 +38,6 @@ namespace rwr {
 
 constexpr float kWfFixedScale = 67108864.0f;  // 2^26: contributions < 64 per ray, 32 samples of them < 2^37
 
-// Direction bin: 3 bits of octant (Gray-coded so that neighbours share two signs) and 6 bits of position inside
-// the octant's triangle of the octahedral map (Morton order of an 8x8 grid).
-RWR_DEV uint32_t direction_bin(f3 D)
-{
-    const uint32_t sx = __float_as_uint(D.x) >> 31, sy = __float_as_uint(D.y) >> 31, sz = __float_as_uint(D.z) >> 31;
-    const uint32_t oct = sz * 4u + (sy ^ sz) * 2u + (sx ^ sy);  // reflected Gray code of (sz, sy, sx)
-    const float ax = fabsf(D.x), ay = fabsf(D.y), az = fabsf(D.z);
-    const float inv = __builtin_amdgcn_rcpf(ax + ay + az + 1e-30f);
-    const uint32_t iu = min(7u, (uint32_t)(ax * inv * 8.0f)), iv = min(7u, (uint32_t)(ay * inv * 8.0f));
-    const uint32_t mu = (iu & 1u) | ((iu & 2u) << 1) | ((iu & 4u) << 2), mv = (iv & 1u) | ((iv & 2u) << 1) | ((iv & 4u) << 2);
-    return oct * 64u + (mu | (mv << 1));
-}
-
 // Per pool, written by k_wf_sort and read by the two trace kernels.
 struct PoolInfo {
     uint32_t n_rays;         // 0: nothing to trace
@@ -163,22 +150,21 @@ k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict_
     }
     // histogram of the direction bins; e = sample * 512 + wave * 128 + k * 64 + lane
     for (uint32_t e0 = tid; e0 < n_slots; e0 += 256u * 8u) {
-        float4 d[8];
+        uint32_t bin[8];   // the primary stage stored every ray's bin beside it: 2 B to read instead of the 32-byte record
         bool live_slot[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const uint32_t e = e0 + 256u * (uint32_t)u;
             live_slot[u] = e < n_slots && ((sh.masks[e >> 6] >> (e & 63u)) & 1ull);
-            d[u] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-            if (live_slot[u]) d[u] = wf.rays[2u * (pool_base + e) + 1u];
+            bin[u] = 0xffffu;
+            if (live_slot[u]) bin[u] = min((uint32_t)wf.bins[pool_base + e], kWfDirBins - 1u);
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const uint32_t e = e0 + 256u * (uint32_t)u;
             if (e < n_slots) {
-                const uint32_t bin = live_slot[u] ? direction_bin(mk3(d[u].x, d[u].y, d[u].z)) : 0xffffu;
-                s_bins[e] = (uint16_t)bin;
-                if (live_slot[u]) atomicAdd(&sh.hist[bin], 1u);
+                s_bins[e] = (uint16_t)bin[u];
+                if (live_slot[u]) atomicAdd(&sh.hist[bin[u]], 1u);
             }
         }
     }
@@ -497,7 +483,7 @@ k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const
         oct = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sh.oct_begin[oct] + (pk - sh.pk_begin[oct]) * 128u));
         const uint32_t last = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.oct_begin[oct + 1]);
-        // Gray-coded octant -> sign bits (kernels: direction_bin): sz = bit 2, sy = bit 1 ^ sz, sx = bit 0 ^ sy
+        // Gray-coded octant -> sign bits (rwr_device.h wf_direction_bin): sz = bit 2, sy = bit 1 ^ sz, sx = bit 0 ^ sy
         const uint32_t sz = oct >> 2, sy = ((oct >> 1) & 1u) ^ sz, sx = (oct & 1u) ^ sy;
 
         // -- the lane's two rays ---------------------------------------------------------------------------------

@@ -323,11 +323,13 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
                     const uint32_t slot = slot_base + lane;
                     wf.rays[2u * slot] = make_float4(O1.x.x, O1.y.x, O1.z.x, wf_pack_unorm16x2(tr.x, tgc.x));
                     wf.rays[2u * slot + 1u] = make_float4(D1.x.x, D1.y.x, D1.z.x, wf_pack_unorm16x2(tb.x, 0.0f));
+                    wf.bins[slot] = (uint16_t)wf_direction_bin(lane3(D1, 0));
                 }
                 if (emit.y) {
                     const uint32_t slot = slot_base + 64u + lane;
                     wf.rays[2u * slot] = make_float4(O1.x.y, O1.y.y, O1.z.y, wf_pack_unorm16x2(tr.y, tgc.y));
                     wf.rays[2u * slot + 1u] = make_float4(D1.x.y, D1.y.y, D1.z.y, wf_pack_unorm16x2(tb.y, 0.0f));
+                    wf.bins[slot] = (uint16_t)wf_direction_bin(lane3(D1, 1));
                 }
             }
         }

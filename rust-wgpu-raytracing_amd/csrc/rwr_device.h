@@ -437,6 +437,20 @@ RWR_DEV f3 bounce_direction(f3 n, uint32_t pixel, uint32_t sample, uint32_t seed
     return normalize3(d);
 }
 
+// Wavefront integrator: the key a tile's ray pool is sorted by (kernels_wf_primary.hip stores it, kernels_wf_bounce.hip sorts).
+// Direction bin: 3 bits of octant (Gray-coded so that neighbours share two signs) and 6 bits of position inside
+// the octant's triangle of the octahedral map (Morton order of an 8x8 grid).
+RWR_DEV uint32_t wf_direction_bin(f3 D)
+{
+    const uint32_t sx = __float_as_uint(D.x) >> 31, sy = __float_as_uint(D.y) >> 31, sz = __float_as_uint(D.z) >> 31;
+    const uint32_t oct = sz * 4u + (sy ^ sz) * 2u + (sx ^ sy);  // reflected Gray code of (sz, sy, sx)
+    const float ax = fabsf(D.x), ay = fabsf(D.y), az = fabsf(D.z);
+    const float inv = __builtin_amdgcn_rcpf(ax + ay + az + 1e-30f);
+    const uint32_t iu = min(7u, (uint32_t)(ax * inv * 8.0f)), iv = min(7u, (uint32_t)(ay * inv * 8.0f));
+    const uint32_t mu = (iu & 1u) | ((iu & 2u) << 1) | ((iu & 4u) << 2), mv = (iv & 1u) | ((iv & 2u) << 1) | ((iv & 4u) << 2);
+    return oct * 64u + (mu | (mv << 1));
+}
+
 // Wavefront ray records (rwr_internal.h WfBuffers::rays): the throughput's three channels as unorm16 in the two w components.
 RWR_DEV float wf_pack_unorm16x2(float a, float b)
 {

@@ -202,6 +202,7 @@ struct WfBuffers {
     unsigned long long *fix;       // 3 planes of W*H: fixed-point (2^-26) sums of albedo(h0) * E(h1), red, green, blue
     float4 *rays;                  // two float4 per slot: {O.xyz, thr.r | thr.g << 16}, {D.xyz, thr.b} (throughput as unorm16)
     unsigned long long *masks;
+    uint16_t *bins;                // per slot: the ray's direction bin (wf_direction_bin; written with the ray, read by the sort)
     uint16_t *sorted;              // per tile: group * 512 pool slots in direction order (scratch of the bounce stage)
     uint32_t *wave_total;          // per tile and wave: bounce rays emitted over all groups of the frame
     uint32_t group;                // samples per launch group this frame
