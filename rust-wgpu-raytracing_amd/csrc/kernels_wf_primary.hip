@@ -181,7 +181,30 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
     f2 ar = splat(0.0f), ag = splat(0.0f), ab = splat(0.0f), aa = splat(0.0f);  // the group's sum of E(h0), alpha
     uint32_t emitted = 0;  // rays this wave emitted in this launch (wave-uniform)
 
-    for (uint32_t sidx = 0; sidx < sample_count; sidx++) {
+    // A tile no face and no sphere can be seen through (conservative bounds: nothing any jittered ray of its pixels could
+    // hit) has nothing to trace in any sample: its pixels keep the clear values.  On a frame that shows a small mesh
+    // that is most tiles.
+    bool empty_tile = CULL && (n_src == 0u || (cached && (cm0 | cm1) == 0ull));
+    if (empty_tile)
+        for (uint32_t s = 0; s < p.n_spheres; s++)
+            if (!((tx0 + kTileWf < p.sphere_rect[s][0]) || (tx0 > p.sphere_rect[s][2]) || (ty0 + kTileHf < p.sphere_rect[s][1]) ||
+                  (ty0 > p.sphere_rect[s][3])))
+                empty_tile = false;
+    if (empty_tile && sample_begin == 0u && in0) {   // sample 0's planes
+        tg.depth[pix0] = 0.0f;
+        if (AUX) { tg.obj_id[pix0] = -1; tg.hit_t[pix0] = 0.0f; }
+        if (in1) {
+            tg.depth[pix0 + 1u] = 0.0f;
+            if (AUX) { tg.obj_id[pix0 + 1u] = -1; tg.hit_t[pix0 + 1u] = 0.0f; }
+        }
+    }
+    if (empty_tile && p.bounces != 0u && lane == 0u)    // nothing emitted: the bounce stage sees empty ballots
+        for (uint32_t sidx = 0; sidx < sample_count; sidx++) {
+            unsigned long long *mk = wf.masks + (size_t)(tile * wf.group + sidx) * 8u + wave * 2u;
+            mk[0] = 0ull; mk[1] = 0ull;
+        }
+
+    for (uint32_t sidx = 0; sidx < (empty_tile ? 0u : sample_count); sidx++) {
         const uint32_t sample = sample_begin + sidx;
         // -- the sample's ray: pixel centre at spp = 1, else two uniforms of the counter-based RNG ---------------
         const u2 base = u2{rng_base(pix0, sample, p.seed), rng_base(pix0 + 1u, sample, p.seed)};
