@@ -127,7 +127,10 @@ struct rwr_context {
     float aabb_lo[3] = {0, 0, 0}, aabb_hi[3] = {0, 0, 0};   // of the (flattened) world-space faces
     float auto_bvh_face_px = 150.0f;   // tunable: RWR_AUTO_BVH_FACE_PX (0 = never pick the BVH kernel by itself)
     // wavefront integrator state
-    DeviceBuffer<float4> d_accum, d_rays;
+    DeviceBuffer<float4> d_rays;
+    bool wf_fix_clean = false;      // the fixed-point planes are all zero (k_wf_resolve leaves them so)
+    uint32_t *h_wf_live = nullptr;  // pinned: live pools of the last launch group {packets, per-lane}, read a frame late
+    uint32_t wf_z_split = 0;        // tunable: RWR_WF_ZSPLIT (0 = from the previous frame's live pools)
     DeviceBuffer<unsigned long long> d_wf_masks;
     DeviceBuffer<uint16_t> d_wf_sorted, d_wf_bins;
     DeviceBuffer<uint32_t> d_wave_total;
@@ -488,6 +491,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     if (const char *e9 = std::getenv("RWR_WF_STATS")) {
         if (std::atoi(e9) && ctx->d_wf_dbg.ensure(4) == hipSuccess) (void)hipMemset(ctx->d_wf_dbg.ptr, 0, 32);
     }
+    if (const char *e12 = std::getenv("RWR_WF_ZSPLIT")) ctx->wf_z_split = (uint32_t)std::strtoul(e12, nullptr, 10);
     if (const char *e10 = std::getenv("RWR_WF_MIN_PACKET_POOLS")) ctx->wf_min_packet_pools = (uint32_t)std::strtoul(e10, nullptr, 10);
     if (const char *e8 = std::getenv("RWR_WF_PACKET_EXTENT")) ctx->wf_packet_extent = (float)std::atof(e8);
     if (const char *e7 = std::getenv("RWR_WF_PACKET_FILL")) ctx->wf_packet_fill = (float)std::atof(e7);
@@ -513,7 +517,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
     ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release(); ctx->d_tangent.release();
     for (auto &t : ctx->d_nmaps) t.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
-    ctx->d_accum.release(); ctx->d_rays.release(); ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wf_bins.release(); ctx->d_wave_total.release(); ctx->d_wf_fix.release(); ctx->d_pool_info.release(); ctx->d_wf_live.release(); ctx->d_pool_list.release(); for (auto &t : ctx->d_texs) t.release();
+    ctx->d_rays.release(); if (ctx->h_wf_live) { (void)hipHostFree(ctx->h_wf_live); ctx->h_wf_live = nullptr; } ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wf_bins.release(); ctx->d_wave_total.release(); ctx->d_wf_fix.release(); ctx->d_pool_info.release(); ctx->d_wf_live.release(); ctx->d_pool_list.release(); for (auto &t : ctx->d_texs) t.release();
     ctx->d_face_mat.release(); ctx->d_materials.release();
     for (FrameSlot &sl : ctx->slots) {
         sl.release_buffers();
@@ -946,35 +950,58 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         const uint32_t group = std::min(rp.spp, ctx->wf_group);
         const uint32_t tiles_x = (ctx->screen.width + kWfTileW - 1u) / kWfTileW, tiles_y = (row_end - row_begin + kWfTileH - 1u) / kWfTileH;
         const uint32_t n_tiles = tiles_x * tiles_y;
-        RWR_HIP_CHECK(ctx->d_accum.ensure(n));
         RWR_HIP_CHECK(ctx->d_wave_total.ensure((size_t)n_tiles * 4u));
+        RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wave_total.ptr, 0, (size_t)n_tiles * 4u * sizeof(uint32_t), stream));
+        if (ctx->d_wf_fix.count < 4u * n) ctx->wf_fix_clean = false;
+        RWR_HIP_CHECK(ctx->d_wf_fix.ensure(4u * n));
+        if (!ctx->wf_fix_clean)   // first use, a new size, or a frame that did not reach its resolve
+            RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wf_fix.ptr, 0, 4u * n * sizeof(unsigned long long), stream));
+        ctx->wf_fix_clean = false;
         if (rp.max_bounces) {
             const size_t slots = (size_t)n_tiles * group * kWfTilePixels;
             RWR_HIP_CHECK(ctx->d_rays.ensure(2u * slots));
             RWR_HIP_CHECK(ctx->d_wf_sorted.ensure(slots));
             RWR_HIP_CHECK(ctx->d_wf_bins.ensure(slots));
             RWR_HIP_CHECK(ctx->d_wf_masks.ensure((size_t)n_tiles * group * 8u));
-            RWR_HIP_CHECK(ctx->d_wf_fix.ensure(3u * n));
             RWR_HIP_CHECK(ctx->d_pool_info.ensure((size_t)n_tiles * wf_pool_info_bytes()));
             RWR_HIP_CHECK(ctx->d_pool_list.ensure(2u * (size_t)n_tiles));
             if (!ctx->d_wf_live.ptr) {
                 RWR_HIP_CHECK(ctx->d_wf_live.ensure(8));
                 RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wf_live.ptr, 0, 8 * sizeof(uint32_t), stream));
             }
+            if (!ctx->h_wf_live) {
+                RWR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_wf_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
+                ctx->h_wf_live[0] = ctx->h_wf_live[1] = 0u;
+            }
         }
-        const WfBuffers wf{ctx->d_accum.ptr, ctx->d_wf_fix.ptr, ctx->d_rays.ptr, ctx->d_wf_masks.ptr, ctx->d_wf_bins.ptr, ctx->d_wf_sorted.ptr,
+        // How many workgroups share a tile's samples in the primary stage: one when the frame fills the chip, more when the
+        // previous frame found only a few live tiles (its count arrives through pinned memory, a frame late, never waited
+        // for).  Any split gives the same frame: all sums are integers.
+        uint32_t z_split = ctx->wf_z_split;
+        if (z_split == 0u) {
+            z_split = 1u;
+            const uint32_t live = ctx->h_wf_live ? ctx->h_wf_live[0] + ctx->h_wf_live[1] : 0u;
+            if (live != 0u && live < 1024u)
+                while (z_split < 8u && z_split * live < 2048u) z_split *= 2u;
+        }
+        const WfBuffers wf{ctx->d_wf_fix.ptr, ctx->d_rays.ptr, ctx->d_wf_masks.ptr, ctx->d_wf_bins.ptr, ctx->d_wf_sorted.ptr,
                            ctx->d_wave_total.ptr, group, tiles_x, ctx->d_wf_dbg.ptr};
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u,
                             ctx->wf_packet_extent * ctx->bvh_leaf_extent, ctx->wf_min_packet_pools};
         for (uint32_t s0 = 0, g = 0; s0 < rp.spp; s0 += group, g++) {
             const uint32_t cnt = std::min(group, rp.spp - s0);
-            RWR_HIP_CHECK(launch_wf_primary(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0, tg, wf, s0, cnt));
-            if (rp.max_bounces)
+            RWR_HIP_CHECK(launch_wf_primary(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0, tg, wf, s0, cnt, z_split));
+            if (rp.max_bounces) {
+                const uint32_t parity = (ctx->wf_parity++) & 1u;
                 RWR_HIP_CHECK(launch_wf_bounce(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh, tex0, wf, n_tiles, cnt,
                                                (uint32_t)std::fmax(1.0f, std::ceil(ctx->wf_packet_fill * (float)(cnt * kWfTilePixels))),
-                                               ctx->d_pool_info.ptr, ctx->d_wf_live.ptr, ctx->d_pool_list.ptr, (ctx->wf_parity++) & 1u));
+                                               ctx->d_pool_info.ptr, ctx->d_wf_live.ptr, ctx->d_pool_list.ptr, parity));
+                if (s0 + group >= rp.spp)   // the last group's live-pool counts, for the next frame's split
+                    RWR_HIP_CHECK(hipMemcpyAsync(ctx->h_wf_live, ctx->d_wf_live.ptr + parity * 4u, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            }
         }
         RWR_HIP_CHECK(launch_wf_resolve(stream, fp, tg, wf));
+        ctx->wf_fix_clean = true;   // (the resolve zeroes what it reads; rows outside the band were never touched)
         ctx->last_spp = rp.spp;
         ctx->last_segments = n_tiles;
         ctx->last_had_bounce = rp.max_bounces != 0;

@@ -96,21 +96,19 @@ hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRec
 
 template <bool AUX>
 __global__ void __launch_bounds__(256)
-k_wf_resolve(const FrameParams p, const Targets tg, const WfBuffers wf)
+k_wf_resolve(const FrameParams p, const Targets tg, WfBuffers wf)
 {
     const uint32_t n = p.width * (p.row_end - p.row_begin);
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint32_t pixel = p.row_begin * p.width + i;
-    float4 acc = wf.accum[pixel];
-    if (p.bounces != 0u) {   // + the bounce stage's fixed-point sums (2^-26 units, kernels_wf_bounce.hip)
-        const size_t plane = (size_t)p.width * p.height;
-        acc.x += (float)wf.fix[pixel] * (1.0f / 67108864.0f);
-        acc.y += (float)wf.fix[plane + pixel] * (1.0f / 67108864.0f);
-        acc.z += (float)wf.fix[2u * plane + pixel] * (1.0f / 67108864.0f);
-    }
-    const float fs = (float)p.spp;
-    const float r = acc.x / fs, g = acc.y / fs, b = acc.z / fs, a = acc.w / fs;
+    // the frame's fixed-point sums (2^-26 units; kernels_wf_primary.hip, kernels_wf_bounce.hip), read and left zeroed for
+    // the next frame
+    const size_t plane = (size_t)p.width * p.height;
+    const float unit = 1.0f / kWfFixedScale, fs = (float)p.spp;
+    const float r = (float)wf.fix[pixel] * unit / fs, g = (float)wf.fix[plane + pixel] * unit / fs;
+    const float b = (float)wf.fix[2u * plane + pixel] * unit / fs, a = (float)wf.fix[3u * plane + pixel] * unit / fs;
+    wf.fix[pixel] = 0ull; wf.fix[plane + pixel] = 0ull; wf.fix[2u * plane + pixel] = 0ull; wf.fix[3u * plane + pixel] = 0ull;
     reinterpret_cast<uint32_t *>(tg.color)[pixel] = pack_rgba8(r, g, b, a);
     if (AUX) reinterpret_cast<float4 *>(tg.color_f32)[pixel] = make_float4(r, g, b, a);
 }

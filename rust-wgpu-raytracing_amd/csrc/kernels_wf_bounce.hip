@@ -36,8 +36,6 @@
 
 namespace rwr {
 
-constexpr float kWfFixedScale = 67108864.0f;  // 2^26: contributions < 64 per ray, 32 samples of them < 2^37
-
 // Per pool, written by k_wf_sort and read by the two trace kernels.
 struct PoolInfo {
     uint32_t n_rays;         // 0: nothing to trace
@@ -237,7 +235,7 @@ RWR_DEV void add_contribution(TraceShared &sh, uint32_t e, float cr, float cg, f
 RWR_DEV void flush_pool(TraceShared &sh, const FrameParams &p, const WfBuffers &wf, uint32_t tile)
 {
     const uint32_t tile_x0 = (tile % wf.tiles_x) * kWfTileW, tile_y0 = p.row_begin + (tile / wf.tiles_x) * kWfTileH;
-    const size_t plane = (size_t)p.width * p.height;
+    const size_t plane = (size_t)p.width * p.height;   // (planes 0..2: red, green, blue; plane 3 is the primary stage's alpha)
     for (uint32_t q = threadIdx.x; q < kWfTilePixels; q += 256u) {
         const uint32_t px = tile_x0 + (q & (kWfTileW - 1u)), py = tile_y0 + q / kWfTileW;
         const unsigned long long sr = sh.acc[q * 3u], sg = sh.acc[q * 3u + 1u], sb = sh.acc[q * 3u + 2u];

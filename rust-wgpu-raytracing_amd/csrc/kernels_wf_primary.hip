@@ -20,6 +20,8 @@
 // for operation like the oracle, so sample-0 planes are bit-exact and every bounce ray is the oracle's.
 #include <hip/hip_ext.h>
 
+#include <algorithm>
+
 #include "rwr_primary.h"
 #include "rwr_shade_p2.h"
 
@@ -127,7 +129,7 @@ template <bool AUX, bool CULL, bool NMAP>
 __global__ void __launch_bounds__(256, (AUX || NMAP) ? 3 : RWR_WF_OCC)
 k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_begin, uint32_t bins_enabled,
              int32_t mesh_x0, int32_t mesh_y0, int32_t mesh_x1, int32_t mesh_y1, uint32_t sample_begin, uint32_t sample_count,
-             const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
+             uint32_t z_split, const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
              const float4 *__restrict__ tex, const Targets tg, const WfBuffers wf)
 {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -178,8 +180,14 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
     const float rw = refined_rcp(fw), rh = refined_rcp(fh);
     const f3 O = ld3(p.cam.origin);
 
-    f2 ar = splat(0.0f), ag = splat(0.0f), ab = splat(0.0f), aa = splat(0.0f);  // the group's sum of E(h0), alpha
+    // the group's sums of E(h0) per pixel as 2^-22 fixed point in 32 bits (a sample's term is capped at 32, so 32 samples
+    // fit; shifted into the planes' 2^-26 units at the end: WfBuffers::fix), and its primary hits
+    uint32_t fr0 = 0, fg0 = 0, fb0 = 0, fr1 = 0, fg1 = 0, fb1 = 0;
+    uint32_t hits0 = 0, hits1 = 0;
     uint32_t emitted = 0;  // rays this wave emitted in this launch (wave-uniform)
+    // z_split workgroups share a tile's samples (sample z, z + z_split, ...): on a frame that shows a small mesh a wave
+    // would otherwise trace all the group's samples one after the other while most of the chip idles
+    const uint32_t z = blockIdx.z;
 
     // A tile no face and no sphere can be seen through (conservative bounds: nothing any jittered ray of its pixels could
     // hit) has nothing to trace in any sample: its pixels keep the clear values.  On a frame that shows a small mesh
@@ -190,7 +198,7 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
             if (!((tx0 + kTileWf < p.sphere_rect[s][0]) || (tx0 > p.sphere_rect[s][2]) || (ty0 + kTileHf < p.sphere_rect[s][1]) ||
                   (ty0 > p.sphere_rect[s][3])))
                 empty_tile = false;
-    if (empty_tile && sample_begin == 0u && in0) {   // sample 0's planes
+    if (empty_tile && sample_begin == 0u && z == 0u && in0) {   // sample 0's planes
         tg.depth[pix0] = 0.0f;
         if (AUX) { tg.obj_id[pix0] = -1; tg.hit_t[pix0] = 0.0f; }
         if (in1) {
@@ -198,13 +206,13 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
             if (AUX) { tg.obj_id[pix0 + 1u] = -1; tg.hit_t[pix0 + 1u] = 0.0f; }
         }
     }
-    if (empty_tile && p.bounces != 0u && lane == 0u)    // nothing emitted: the bounce stage sees empty ballots
+    if (empty_tile && p.bounces != 0u && lane == 0u && z == 0u)    // nothing emitted: the bounce stage sees empty ballots
         for (uint32_t sidx = 0; sidx < sample_count; sidx++) {
             unsigned long long *mk = wf.masks + (size_t)(tile * wf.group + sidx) * 8u + wave * 2u;
             mk[0] = 0ull; mk[1] = 0ull;
         }
 
-    for (uint32_t sidx = 0; sidx < (empty_tile ? 0u : sample_count); sidx++) {
+    for (uint32_t sidx = z; sidx < (empty_tile ? 0u : sample_count); sidx += z_split) {
         const uint32_t sample = sample_begin + sidx;
         // -- the sample's ray: pixel centre at spp = 1, else two uniforms of the counter-based RNG ---------------
         const u2 base = u2{rng_base(pix0, sample, p.seed), rng_base(pix0 + 1u, sample, p.seed)};
@@ -315,8 +323,15 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
             }
         }
         const i2 hit = obj != -1;
-        ar += hit ? cr : splat(0.0f); ag += hit ? cg : splat(0.0f); ab += hit ? cb : splat(0.0f);
-        aa += hit ? splat(2.0f) : splat(0.0f);   // alpha 1 + 1 on a written pixel (compute.wgsl:231-234)
+        {   // (cr, cg, cb are 0 where nothing was hit; float -> u32 conversion sends NaN / negatives to 0; alpha is 1 + 1 on a
+            // written pixel, :231-234)
+            constexpr float kScale22 = kWfFixedScale / 16.0f;
+            constexpr uint32_t kCap = (32u << 22) - 1u;
+            const f2 sr = cr * kScale22, sg = cg * kScale22, sb = cb * kScale22;
+            fr0 += min((uint32_t)sr.x, kCap); fg0 += min((uint32_t)sg.x, kCap); fb0 += min((uint32_t)sb.x, kCap);
+            fr1 += min((uint32_t)sr.y, kCap); fg1 += min((uint32_t)sg.y, kCap); fb1 += min((uint32_t)sb.y, kCap);
+            hits0 += hit.x ? 1u : 0u; hits1 += hit.y ? 1u : 0u;
+        }
 
         // -- bounce ray of every pixel that hit something ----------------------------------------------------------
         if (p.bounces != 0u) {
@@ -358,41 +373,36 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
         }
     }
 
-    // -- the accumulator: read and written once per group -----------------------------------------------------------
-    if (in0) {
-        float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0;
-        if (sample_begin != 0u) {
-            a0 = wf.accum[pix0];
-            if (in1) a1 = wf.accum[pix0 + 1u];
-        }
-        a0.x += ar.x; a0.y += ag.x; a0.z += ab.x; a0.w += aa.x;
-        wf.accum[pix0] = a0;
-        if (sample_begin == 0u && p.bounces != 0u) {   // the frame's fixed-point bounce sums start at 0
-            const size_t plane = (size_t)p.width * p.height;
-            wf.fix[pix0] = 0ull; wf.fix[plane + pix0] = 0ull; wf.fix[2u * plane + pix0] = 0ull;
-            if (in1) { wf.fix[pix0 + 1u] = 0ull; wf.fix[plane + pix0 + 1u] = 0ull; wf.fix[2u * plane + pix0 + 1u] = 0ull; }
-        }
-        if (in1) {
-            a1.x += ar.y; a1.y += ag.y; a1.z += ab.y; a1.w += aa.y;
-            wf.accum[pix0 + 1u] = a1;
+    // -- the frame's fixed-point sums: once per group and pixel (plain read-modify-write when this workgroup owns the tile's
+    // samples alone, integer atomics when it shares them: the same bits either way) ------------------------------------------
+    if (in0 && !empty_tile) {
+        const size_t plane = (size_t)p.width * p.height;
+        const unsigned long long fa0 = (unsigned long long)hits0 * (unsigned long long)(2.0f * kWfFixedScale);
+        const unsigned long long fa1 = (unsigned long long)hits1 * (unsigned long long)(2.0f * kWfFixedScale);
+        const unsigned long long r0 = (unsigned long long)fr0 << 4, g0 = (unsigned long long)fg0 << 4, b0 = (unsigned long long)fb0 << 4;
+        const unsigned long long r1 = (unsigned long long)fr1 << 4, g1 = (unsigned long long)fg1 << 4, b1 = (unsigned long long)fb1 << 4;
+        if (z_split == 1u) {
+            wf.fix[pix0] += r0; wf.fix[plane + pix0] += g0; wf.fix[2u * plane + pix0] += b0; wf.fix[3u * plane + pix0] += fa0;
+            if (in1) { wf.fix[pix0 + 1u] += r1; wf.fix[plane + pix0 + 1u] += g1; wf.fix[2u * plane + pix0 + 1u] += b1; wf.fix[3u * plane + pix0 + 1u] += fa1; }
+        } else {
+            if (hits0) { atomicAdd(&wf.fix[pix0], r0); atomicAdd(&wf.fix[plane + pix0], g0); atomicAdd(&wf.fix[2u * plane + pix0], b0); atomicAdd(&wf.fix[3u * plane + pix0], fa0); }
+            if (in1 && hits1) { atomicAdd(&wf.fix[pix0 + 1u], r1); atomicAdd(&wf.fix[plane + pix0 + 1u], g1); atomicAdd(&wf.fix[2u * plane + pix0 + 1u], b1); atomicAdd(&wf.fix[3u * plane + pix0 + 1u], fa1); }
         }
     }
-    if (lane == 0u) {
-        uint32_t *wt = wf.wave_total + tile * 4u + wave;
-        *wt = (sample_begin == 0u ? 0u : *wt) + emitted;
-    }
+    if (lane == 0u && emitted) atomicAdd(wf.wave_total + tile * 4u + wave, emitted);   // (zeroed when the frame starts)
 }
 
 hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                              const FrameTri *ftris, const float4 *tex, const Targets &tg, const WfBuffers &wf,
-                             uint32_t sample_begin, uint32_t sample_count)
+                             uint32_t sample_begin, uint32_t sample_count, uint32_t z_split)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0 || sample_count == 0) return hipSuccess;
-    const dim3 grid((fp.width + kWfTileW - 1u) / kWfTileW, (fp.row_end - fp.row_begin + kWfTileH - 1u) / kWfTileH);
+    z_split = std::max(1u, std::min(z_split, sample_count));
+    const dim3 grid((fp.width + kWfTileW - 1u) / kWfTileW, (fp.row_end - fp.row_begin + kWfTileH - 1u) / kWfTileH, z_split);
     const dim3 block(256);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0, do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
 #define RWR_WF_ARGS ftris, fp.n_tris, fp.row_begin, fp.bins.enabled, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], \
-                    sample_begin, sample_count, fp, tris, shade, tex, tg, wf
+                    sample_begin, sample_count, z_split, fp, tris, shade, tex, tg, wf
     const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0;
 #define RWR_WF_LAUNCH(A, C, N) hipLaunchKernelGGL((k_wf_primary<A, C, N>), grid, block, 0, s, RWR_WF_ARGS)
     if (nmap) {

@@ -196,10 +196,12 @@ hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, co
 // lanes that emitted.  The bounce stage compacts a pool by those ballots while sorting it by direction.
 constexpr uint32_t kWfTileW = 64, kWfTileH = 8, kWfTilePixels = kWfTileW * kWfTileH;
 constexpr uint32_t kWfMaxGroup = 32;          // samples per launch group (LDS of the bounce stage is sized for it)
+constexpr float kWfFixedScale = 67108864.0f;  // 2^26: a term < 64, thousands of them < 2^64
 constexpr uint32_t kWfDirBins = 512;          // 8 octants x 8x8 cells of the octahedral map
 struct WfBuffers {
-    float4 *accum;                 // W*H RGBA32F running sums of the first hits' E(h0) (a = 2 * primary hits)
-    unsigned long long *fix;       // 3 planes of W*H: fixed-point (2^-26) sums of albedo(h0) * E(h1), red, green, blue
+    unsigned long long *fix;       // 4 planes of W*H: the frame's radiance sums as 2^-26 FIXED POINT — red, green, blue of
+                                   // E(h0) + albedo(h0) * E(h1) over all samples, and alpha (2 per primary hit).  Integer sums are
+                                   // the same bits in whatever order and by whichever workgroups they are added.
     float4 *rays;                  // two float4 per slot: {O.xyz, thr.r | thr.g << 16}, {D.xyz, thr.b} (throughput as unorm16)
     unsigned long long *masks;
     uint16_t *bins;                // per slot: the ray's direction bin (wf_direction_bin; written with the ray, read by the sort)
@@ -224,7 +226,7 @@ hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriReco
                              hipEvent_t ev_stop = nullptr);
 hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                              const FrameTri *ftris, const float4 *tex, const Targets &tg,
-                             const WfBuffers &wf, uint32_t sample_begin, uint32_t sample_count);
+                             const WfBuffers &wf, uint32_t sample_begin, uint32_t sample_count, uint32_t z_split);
 hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                             const BvhDevice &bvh, const float4 *tex, const WfBuffers &wf,
                             uint32_t n_tiles, uint32_t sample_count, uint32_t packet_min_rays, void *pool_info, uint32_t *counters,
