@@ -29,6 +29,7 @@
 // their nearest hits are exact, so the stage's output differs from the oracle's only by float summation order
 // (tolerance 1e-4).
 #include <algorithm>
+#include <type_traits>
 
 #include "rwr_bvh.h"
 #include "rwr_primary.h"
@@ -46,7 +47,9 @@ struct PoolInfo {
 static_assert(sizeof(PoolInfo) == 48, "PoolInfo is 48 B");
 
 constexpr uint32_t kWfMaxSplit = 32;       // at most this many work items share one pool
-constexpr uint32_t kWfTargetItems = 4096;  // work items a trace launch should have (16 per CU)
+constexpr uint32_t kWfTargetItems = 16384; // work items a trace launch should have (64 per CU: one 256-ray chunk each when pools are few)
+constexpr uint32_t kWfWholePools = 1024;   // this many live pools keep the chip busy by themselves
+constexpr uint32_t kWfTargetItemsDense = 4096;
 constexpr uint32_t kWfTraceGroups = 2048;  // workgroups of a trace launch (persistent: they pull work items)
 // Fewer packet pools than `min_packet_pools` (default 128, BvhDevice) in a launch group: the per-lane kernel takes them
 // (a packet is one long chain of dependent scalar loads; a handful of them on an otherwise idle chip take longer
@@ -67,7 +70,11 @@ RWR_DEV float key_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ?
 // screen: otherwise four waves would walk through a pool of thousands of rays one after the other while 250 CUs idle).
 RWR_DEV uint32_t pool_split(uint32_t live)
 {
-    return live == 0u ? 1u : min(kWfMaxSplit, max(1u, (kWfTargetItems + live - 1u) / live));
+    if (live == 0u) return 1u;
+    // many pools: just enough pieces that the last round of work items is short (measured at configs[2], 4 050 pools: two
+    // shares beat one by 8 % and five by 6 % — every share flushes its sums); few pools: one 256-ray chunk per item
+    const uint32_t target = live >= kWfWholePools ? kWfTargetItemsDense : kWfTargetItems;
+    return min(kWfMaxSplit, max(1u, (target + live - 1u) / live));
 }
 
 struct SortShared {
@@ -281,7 +288,8 @@ RWR_DEV bool next_item(TraceShared &sh, const PoolInfo *__restrict__ info, uint3
 // ---------------------------------------------------------------------------------------------------------------
 // Pools that are sparse or spread out (silhouette tiles, distant instances): one ray per lane, per-lane BVH
 // traversal with the nodelets and the traversal stacks in LDS (rwr_bvh.h).
-template <bool NODES_IN_LDS, bool NMAP>
+// STACK16: 16-bit traversal stack entries (rwr_bvh.h) for scenes of at most 4 095 faces and 32 767 nodes.
+template <bool NODES_IN_LDS, bool NMAP, bool STACK16>
 __global__ void __launch_bounds__(256)
 k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
                 const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf, const PoolInfo *__restrict__ info,
@@ -293,7 +301,8 @@ k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const S
     // LDS carve of the dynamic part: [nodelets][traversal stack]
     BvhNode4 *s_nodes = reinterpret_cast<BvhNode4 *>(s_dyn);
     const uint32_t node_bytes = NODES_IN_LDS ? bvh.n_nodes * (uint32_t)sizeof(BvhNode4) : 0u;
-    uint32_t *s_stack = reinterpret_cast<uint32_t *>(s_dyn + node_bytes);
+    typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type StackT;
+    StackT *s_stack = reinterpret_cast<StackT *>(s_dyn + node_bytes);
     bool staged = false;
     uint32_t tile, share, n_shares;
     PoolInfo pi;
@@ -641,15 +650,17 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
         if (nmap) hipLaunchKernelGGL((k_wf_trace_packet<true>), grid, dim3(256), 0, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles);
         else hipLaunchKernelGGL((k_wf_trace_packet<false>), grid, dim3(256), 0, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles);
     }
-    const size_t fixed = (size_t)bvh.stack_depth * 256u * 4u;
+    const bool stack16 = bvh.n_nodes <= 0x7fffu && fp.n_tris <= 4095u;   // node indices and leaf links (first << 3 | count - 1) in 15 bits
+    const size_t fixed = (size_t)bvh.stack_depth * 256u * (stack16 ? 2u : 4u);
     const size_t node_bytes = (size_t)bvh.n_nodes * sizeof(BvhNode4);
     // nodelets go to LDS when the workgroup then still fits a CU at least four times (160 KiB LDS, 12 KiB static)
-#define RWR_LANE_LAUNCH(L, N, BYTES) hipLaunchKernelGGL((k_wf_trace_lane<L, N>), grid, dim3(256), BYTES, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles)
-    if (node_bytes + fixed <= 28u * 1024u) {
-        if (nmap) RWR_LANE_LAUNCH(true, true, node_bytes + fixed); else RWR_LANE_LAUNCH(true, false, node_bytes + fixed);
-    } else {
-        if (nmap) RWR_LANE_LAUNCH(false, true, fixed); else RWR_LANE_LAUNCH(false, false, fixed);
-    }
+#define RWR_LANE_LAUNCH(L, N, S16, BYTES) hipLaunchKernelGGL((k_wf_trace_lane<L, N, S16>), grid, dim3(256), BYTES, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles)
+#define RWR_LANE_LAUNCH2(L, BYTES) \
+    if (nmap) { if (stack16) RWR_LANE_LAUNCH(L, true, true, BYTES); else RWR_LANE_LAUNCH(L, true, false, BYTES); } \
+    else { if (stack16) RWR_LANE_LAUNCH(L, false, true, BYTES); else RWR_LANE_LAUNCH(L, false, false, BYTES); }
+    if (node_bytes + fixed <= 28u * 1024u) { RWR_LANE_LAUNCH2(true, node_bytes + fixed) }
+    else { RWR_LANE_LAUNCH2(false, fixed) }
+#undef RWR_LANE_LAUNCH2
 #undef RWR_LANE_LAUNCH
     return hipGetLastError();
 }

@@ -86,8 +86,16 @@ RWR_DEV float f4at(const float4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y 
 // minimum of keys (entry distance bits with the slot in the low 2 bits) — no sorting network;
 // the other survivors are pushed unordered.  (An empty slot's inverted box does NOT fail a
 // min/max slab test by itself: the link is tested.)
-template <typename NodePtr>
-RWR_DEV bool bvh_inner_step(NodePtr nodes, const SlabRay &sr, float tbest, uint32_t &cur, uint32_t *&sp, uint32_t *sp0,
+// Stack entries: child links as they are (uint32_t), or squeezed into 16 bits (uint16_t) for scenes whose node indices
+// and leaf links fit 15 bits — half the LDS, half again as many workgroups per CU for a traversal that waits on memory.
+template <typename StackT> RWR_DEV StackT bvh_stack_enc(uint32_t link);
+template <> RWR_DEV uint32_t bvh_stack_enc<uint32_t>(uint32_t link) { return link; }
+template <> RWR_DEV uint16_t bvh_stack_enc<uint16_t>(uint32_t link) { return (uint16_t)((link & kBvhLeafBit) ? (0x8000u | (link & 0x7fffu)) : link); }
+RWR_DEV uint32_t bvh_stack_dec(uint32_t e) { return e; }
+RWR_DEV uint32_t bvh_stack_dec(uint16_t e) { return (e & 0x8000u) ? (kBvhLeafBit | (uint32_t)(e & 0x7fffu)) : (uint32_t)e; }
+
+template <typename NodePtr, typename StackT>
+RWR_DEV bool bvh_inner_step(NodePtr nodes, const SlabRay &sr, float tbest, uint32_t &cur, StackT *&sp, StackT *sp0,
                             uint32_t stride)
 {
     uint32_t key[4], child[4];
@@ -114,7 +122,7 @@ RWR_DEV bool bvh_inner_step(NodePtr nodes, const SlabRay &sr, float tbest, uint3
     if (kmin == 0xffffffffu) {  // nothing survived: pop
         if (sp == sp0) return false;
         sp -= stride;
-        cur = *sp;
+        cur = bvh_stack_dec(*sp);
         return true;
     }
     const uint32_t near_slot = kmin & 3u;
@@ -122,7 +130,7 @@ RWR_DEV bool bvh_inner_step(NodePtr nodes, const SlabRay &sr, float tbest, uint3
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         if ((uint32_t)i == near_slot) next = child[i];
-        else if (key[i] != 0xffffffffu) { *sp = child[i]; sp += stride; }
+        else if (key[i] != 0xffffffffu) { *sp = bvh_stack_enc<StackT>(child[i]); sp += stride; }
     }
     cur = next;
     return true;
@@ -130,8 +138,9 @@ RWR_DEV bool bvh_inner_step(NodePtr nodes, const SlabRay &sr, float tbest, uint3
 
 // One leaf visit of one lane: exact tests of the leaf's faces, then pop.  Returns false when
 // the lane's traversal is finished.
+template <typename StackT>
 RWR_DEV bool bvh_leaf_step(const uint32_t *__restrict__ leaf_faces, const TriRecord *__restrict__ tris, uint32_t n_faces,
-                           f3 O, f3 D, MeshHit &best, uint32_t &cur, uint32_t *&sp, uint32_t *sp0, uint32_t stride)
+                           f3 O, f3 D, MeshHit &best, uint32_t &cur, StackT *&sp, StackT *sp0, uint32_t stride)
 {
     const uint32_t first = (cur & ~kBvhLeafBit) >> 3, count = (cur & 7u) + 1u;
     for (uint32_t k = 0; k < count; k++) {
@@ -141,7 +150,7 @@ RWR_DEV bool bvh_leaf_step(const uint32_t *__restrict__ leaf_faces, const TriRec
     }
     if (sp == sp0) return false;
     sp -= stride;
-    cur = *sp;
+    cur = bvh_stack_dec(*sp);
     return true;
 }
 
@@ -150,14 +159,14 @@ RWR_DEV bool bvh_leaf_step(const uint32_t *__restrict__ leaf_faces, const TriRec
 // (the host sizes it: a 4-wide node pushes at most 3 entries beyond the one it pops).
 // "while-while" shape: every lane first walks inner nodes until it holds a leaf (or runs
 // dry), then the wave tests leaves together.
-template <typename NodePtr>
+template <typename NodePtr, typename StackT>
 RWR_DEV void bvh_nearest(NodePtr nodes, const uint32_t *__restrict__ leaf_faces, const TriRecord *__restrict__ tris,
-                         uint32_t n_faces, uint32_t *stack, f3 O, f3 D, MeshHit &best)
+                         uint32_t n_faces, StackT *stack, f3 O, f3 D, MeshHit &best)
 {
     const SlabRay sr = make_slab_ray(O, D);
     const uint32_t stride = blockDim.x;
-    uint32_t *sp = stack + threadIdx.x;  // next free slot of this lane's stack
-    uint32_t *const sp0 = sp;
+    StackT *sp = stack + threadIdx.x;  // next free slot of this lane's stack
+    StackT *const sp0 = sp;
     uint32_t cur = 0;  // the root is always an inner node
     bool have_cur = true;
     while (__any(have_cur)) {
