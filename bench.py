@@ -197,16 +197,17 @@ def main() -> int:
     barrier()
 
     # timed region: exactly K steps.  Nothing but the frames themselves is enqueued inside it: the two
-    # HIP events of timer_begin / timer_end sit on the launch stream before the first and after the last frame.
+    # HIP events of timer_begin / timer_stop sit on the launch stream before the first and after the last frame.
     ctx.set_kernel_timing(0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ctx.timer_begin()            # HIP events on the launch stream(s); timer_end joins every frame in flight
+    ctx.timer_begin()            # HIP events on the launch stream(s); timer_stop joins every frame in flight
     for _ in range(args.steps):
         step()
-    dev_ms = ctx.timer_end()
+    ctx.timer_stop()             # enqueues the end event; the one host wait of the region is the synchronize below
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    dev_ms = ctx.timer_elapsed()
     barrier()
 
     # ---- everything below is OUTSIDE the timed region --------------------------------------------

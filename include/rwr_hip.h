@@ -297,6 +297,10 @@ RWR_API int rwr_dist_destroy(rwr_context *ctx);
  * is in flight and records; rwr_timer_end joins every frame in flight into the end event. */
 RWR_API int rwr_timer_begin(rwr_context *ctx);
 RWR_API int rwr_timer_end(rwr_context *ctx, float *elapsed_ms); /* synchronises on the end event */
+/* The same end in two halves, for a caller that waits for the device itself: rwr_timer_stop only
+ * enqueues the end event (no host wait), rwr_timer_elapsed waits for it and reads the interval. */
+RWR_API int rwr_timer_stop(rwr_context *ctx);
+RWR_API int rwr_timer_elapsed(rwr_context *ctx, float *elapsed_ms);
 
 /* Per-kernel timing for roofline accounting: when every_n > 0, every n-th render call
  * brackets its DOMINANT kernel (k_primary; for the wavefront integrator all sample passes of

@@ -103,7 +103,7 @@ def lib() -> C.CDLL:
         "rwr_scene_set_spheres": [vp, vp, u32], "rwr_scene_set_triangles": [vp, vp, u32], "rwr_scene_set_instances": [vp, vp, u32],
         "rwr_resize": [vp, vp], "rwr_render": [vp, vp, vp], "rwr_render_rows": [vp, vp, vp, u32, u32],
         "rwr_synchronize": [vp], "rwr_readback": [vp, vp, vp, vp, vp, vp], "rwr_get_device_targets": [vp, vp, vp],
-        "rwr_timer_begin": [vp], "rwr_timer_end": [vp, vp], "rwr_last_render_stats": [vp, vp, vp],
+        "rwr_timer_begin": [vp], "rwr_timer_end": [vp, vp], "rwr_timer_stop": [vp], "rwr_timer_elapsed": [vp, vp], "rwr_last_render_stats": [vp, vp, vp],
         "rwr_camera_build_inv_uniform": [vp, vp], "rwr_circle_controller_update": [f32, u32, vp],
         "rwr_load_model_compute": [C.c_char_p, C.c_char_p, vp], "rwr_model_free": [vp],
         "rwr_model_info": [vp, vp, vp, vp, vp, vp, vp], "rwr_scene_upload_model": [vp, vp],
@@ -425,6 +425,15 @@ class Context:
     def timer_end(self) -> float:
         ms = C.c_float()
         _check(lib().rwr_timer_end(self._h, C.byref(ms)))
+        return ms.value
+
+    def timer_stop(self):
+        """Enqueue the end event of the interval without waiting for it (rwr_timer_stop)."""
+        _check(lib().rwr_timer_stop(self._h))
+
+    def timer_elapsed(self) -> float:
+        ms = C.c_float()
+        _check(lib().rwr_timer_elapsed(self._h, C.byref(ms)))
         return ms.value
 
     def set_frames_in_flight(self, n: int):

@@ -1115,6 +1115,27 @@ int rwr_timer_end(rwr_context *ctx, float *elapsed_ms)
     return RWR_OK;
 }
 
+int rwr_timer_stop(rwr_context *ctx)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    DeviceGuard g(ctx->device);
+    for (uint32_t i = 1; i < ctx->n_slots; i++) {
+        RWR_HIP_CHECK(hipEventRecord(ctx->slots[i].done, ctx->slots[i].stream));
+        RWR_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->slots[i].done, 0));
+    }
+    RWR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
+    return RWR_OK;
+}
+
+int rwr_timer_elapsed(rwr_context *ctx, float *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
+    DeviceGuard g(ctx->device);
+    RWR_HIP_CHECK(hipEventSynchronize(ctx->ev_end));
+    RWR_HIP_CHECK(hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
+    return RWR_OK;
+}
+
 int rwr_ctx_set_kernel_timing(rwr_context *ctx, uint32_t every_n)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
