@@ -136,13 +136,19 @@ struct rwr_context {
     DeviceBuffer<uint32_t> d_wave_total;
     DeviceBuffer<unsigned long long> d_wf_fix;   // fixed-point bounce sums, 3 planes
     DeviceBuffer<uint8_t> d_pool_info;
-    DeviceBuffer<uint32_t> d_wf_live;            // device counters of the bounce stage, two sets of four
+    DeviceBuffer<uint32_t> d_wf_live;            // device counters of the bounce stage, a set of four per ray queue
     DeviceBuffer<uint32_t> d_pool_list;          // live pools by class, 2 x tiles
     DeviceBuffer<unsigned long long> d_wf_dbg;   // RWR_WF_STATS=1: pool classification counters, printed at destroy
-    uint32_t wf_group = 16;         // samples per launch group; tunable: RWR_WF_GROUP (1..32)
+    uint32_t wf_group = 32;         // samples per launch group; tunable: RWR_WF_GROUP (1..32)
     float wf_packet_fill = 0.25f;   // pools filled at least this much are traced as packets; tunable: RWR_WF_PACKET_FILL (> 1: never)
     uint32_t last_segments = 0;     // tiles of the last wavefront frame
-    uint32_t wf_parity = 0;         // which pair of live-pool counters the next launch group uses
+    // Launch groups alternate between the frame's stream and this one, each with its own half of the ray queue: the
+    // latency-bound ends of one group (the sort, the last packets) run beside the other group's arithmetic.
+    static constexpr uint32_t kWfMaxQueues = 4;
+    hipStream_t wf_streams[kWfMaxQueues] = {};   // [0] unused: queue 0 runs on the frame's stream
+    hipEvent_t wf_fork = nullptr, wf_join[kWfMaxQueues] = {};
+    uint32_t wf_queues = 2;         // tunable: RWR_WF_OVERLAP (1 puts every launch group on the frame's stream; measured at
+                                    // configs[2] / [4]: two queues -6.5 % / -9.5 %, three and four less, a staggered start less)
     uint32_t last_spp = 0;
     bool last_had_bounce = false;
     // one decoded texture per scene part (texels decoded to linear f32 at upload, Rgba8UnormSrgb semantics)
@@ -491,6 +497,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     if (const char *e9 = std::getenv("RWR_WF_STATS")) {
         if (std::atoi(e9) && ctx->d_wf_dbg.ensure(4) == hipSuccess) (void)hipMemset(ctx->d_wf_dbg.ptr, 0, 32);
     }
+    if (const char *e13 = std::getenv("RWR_WF_OVERLAP")) ctx->wf_queues = std::min(rwr_context::kWfMaxQueues, std::max(1u, (uint32_t)std::strtoul(e13, nullptr, 10)));
     if (const char *e12 = std::getenv("RWR_WF_ZSPLIT")) ctx->wf_z_split = (uint32_t)std::strtoul(e12, nullptr, 10);
     if (const char *e10 = std::getenv("RWR_WF_MIN_PACKET_POOLS")) ctx->wf_min_packet_pools = (uint32_t)std::strtoul(e10, nullptr, 10);
     if (const char *e8 = std::getenv("RWR_WF_PACKET_EXTENT")) ctx->wf_packet_extent = (float)std::atof(e8);
@@ -517,6 +524,11 @@ void rwr_ctx_destroy(rwr_context *ctx)
     ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release(); ctx->d_tangent.release();
     for (auto &t : ctx->d_nmaps) t.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
+    for (uint32_t q = 0; q < rwr_context::kWfMaxQueues; q++) {
+        if (ctx->wf_streams[q]) { (void)hipStreamSynchronize(ctx->wf_streams[q]); (void)hipStreamDestroy(ctx->wf_streams[q]); ctx->wf_streams[q] = nullptr; }
+        if (ctx->wf_join[q]) { (void)hipEventDestroy(ctx->wf_join[q]); ctx->wf_join[q] = nullptr; }
+    }
+    if (ctx->wf_fork) { (void)hipEventDestroy(ctx->wf_fork); ctx->wf_fork = nullptr; }
     ctx->d_rays.release(); if (ctx->h_wf_live) { (void)hipHostFree(ctx->h_wf_live); ctx->h_wf_live = nullptr; } ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wf_bins.release(); ctx->d_wave_total.release(); ctx->d_wf_fix.release(); ctx->d_pool_info.release(); ctx->d_wf_live.release(); ctx->d_pool_list.release(); for (auto &t : ctx->d_texs) t.release();
     ctx->d_face_mat.release(); ctx->d_materials.release();
     for (FrameSlot &sl : ctx->slots) {
@@ -957,17 +969,25 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         if (!ctx->wf_fix_clean)   // first use, a new size, or a frame that did not reach its resolve
             RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wf_fix.ptr, 0, 4u * n * sizeof(unsigned long long), stream));
         ctx->wf_fix_clean = false;
+        // two launch groups in flight (each on its own stream, with its own half of the queue) when the frame has several
+        const size_t n_queues = rp.max_bounces ? std::min<size_t>(ctx->wf_queues, (rp.spp + group - 1u) / group) : 1u;
+        const bool overlap = n_queues > 1u;
+        const size_t slots = (size_t)n_tiles * group * kWfTilePixels;
         if (rp.max_bounces) {
-            const size_t slots = (size_t)n_tiles * group * kWfTilePixels;
-            RWR_HIP_CHECK(ctx->d_rays.ensure(2u * slots));
-            RWR_HIP_CHECK(ctx->d_wf_sorted.ensure(slots));
-            RWR_HIP_CHECK(ctx->d_wf_bins.ensure(slots));
-            RWR_HIP_CHECK(ctx->d_wf_masks.ensure((size_t)n_tiles * group * 8u));
-            RWR_HIP_CHECK(ctx->d_pool_info.ensure((size_t)n_tiles * wf_pool_info_bytes()));
-            RWR_HIP_CHECK(ctx->d_pool_list.ensure(2u * (size_t)n_tiles));
+            RWR_HIP_CHECK(ctx->d_rays.ensure(n_queues * 2u * slots));
+            RWR_HIP_CHECK(ctx->d_wf_sorted.ensure(n_queues * slots));
+            RWR_HIP_CHECK(ctx->d_wf_bins.ensure(n_queues * slots));
+            RWR_HIP_CHECK(ctx->d_wf_masks.ensure(n_queues * n_tiles * group * 8u));
+            RWR_HIP_CHECK(ctx->d_pool_info.ensure(n_queues * n_tiles * wf_pool_info_bytes()));
+            RWR_HIP_CHECK(ctx->d_pool_list.ensure(n_queues * 2u * (size_t)n_tiles));
+            if (overlap && !ctx->wf_fork) RWR_HIP_CHECK(hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming));
+            for (size_t q = 0; q < n_queues; q++) {
+                if (q && !ctx->wf_streams[q]) RWR_HIP_CHECK(hipStreamCreateWithFlags(&ctx->wf_streams[q], hipStreamNonBlocking));
+                if (q && !ctx->wf_join[q]) RWR_HIP_CHECK(hipEventCreateWithFlags(&ctx->wf_join[q], hipEventDisableTiming));
+            }
             if (!ctx->d_wf_live.ptr) {
-                RWR_HIP_CHECK(ctx->d_wf_live.ensure(8));
-                RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wf_live.ptr, 0, 8 * sizeof(uint32_t), stream));
+                RWR_HIP_CHECK(ctx->d_wf_live.ensure(4u * rwr_context::kWfMaxQueues));
+                RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wf_live.ptr, 0, 4u * rwr_context::kWfMaxQueues * sizeof(uint32_t), stream));
             }
             if (!ctx->h_wf_live) {
                 RWR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_wf_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
@@ -984,23 +1004,44 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
             if (live != 0u && live < 1024u)
                 while (z_split < 8u && z_split * live < 2048u) z_split *= 2u;
         }
-        const WfBuffers wf{ctx->d_wf_fix.ptr, ctx->d_rays.ptr, ctx->d_wf_masks.ptr, ctx->d_wf_bins.ptr, ctx->d_wf_sorted.ptr,
-                           ctx->d_wave_total.ptr, group, tiles_x, ctx->d_wf_dbg.ptr};
+        // queue q: its half of every per-group buffer and its set of four counters (the primary stage zeroes the set it
+        // is about to fill).  With one queue the frame's sums are read-modify-written by the tile's only workgroup; with
+        // two, a group's primary stage runs beside the other group's trace kernels and everybody adds atomically.
+        WfBuffers wfq[rwr_context::kWfMaxQueues];
+        for (size_t q = 0; q < n_queues; q++) {
+            const size_t h = q;
+            wfq[q] = WfBuffers{ctx->d_wf_fix.ptr,
+                               ctx->d_rays.ptr ? ctx->d_rays.ptr + h * 2u * slots : nullptr,
+                               ctx->d_wf_masks.ptr ? ctx->d_wf_masks.ptr + h * n_tiles * group * 8u : nullptr,
+                               ctx->d_wf_bins.ptr ? ctx->d_wf_bins.ptr + h * slots : nullptr,
+                               ctx->d_wf_sorted.ptr ? ctx->d_wf_sorted.ptr + h * slots : nullptr,
+                               ctx->d_wave_total.ptr, group, tiles_x, ctx->d_wf_dbg.ptr,
+                               rp.max_bounces ? ctx->d_wf_live.ptr + h * 4u : nullptr, overlap ? 1u : 0u};
+        }
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u,
                             ctx->wf_packet_extent * ctx->bvh_leaf_extent, ctx->wf_min_packet_pools};
+        if (overlap) {   // the other streams start behind this frame's setup (and so behind the previous frame's resolve)
+            RWR_HIP_CHECK(hipEventRecord(ctx->wf_fork, stream));
+            for (size_t q = 1; q < n_queues; q++) RWR_HIP_CHECK(hipStreamWaitEvent(ctx->wf_streams[q], ctx->wf_fork, 0));
+        }
         for (uint32_t s0 = 0, g = 0; s0 < rp.spp; s0 += group, g++) {
             const uint32_t cnt = std::min(group, rp.spp - s0);
-            RWR_HIP_CHECK(launch_wf_primary(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0, tg, wf, s0, cnt, z_split));
+            const size_t q = g % n_queues;
+            hipStream_t gs = q ? ctx->wf_streams[q] : stream;
+            RWR_HIP_CHECK(launch_wf_primary(gs, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0, tg, wfq[q], s0, cnt, z_split));
             if (rp.max_bounces) {
-                const uint32_t parity = (ctx->wf_parity++) & 1u;
-                RWR_HIP_CHECK(launch_wf_bounce(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh, tex0, wf, n_tiles, cnt,
+                RWR_HIP_CHECK(launch_wf_bounce(gs, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh, tex0, wfq[q], n_tiles, cnt,
                                                (uint32_t)std::fmax(1.0f, std::ceil(ctx->wf_packet_fill * (float)(cnt * kWfTilePixels))),
-                                               ctx->d_pool_info.ptr, ctx->d_wf_live.ptr, ctx->d_pool_list.ptr, parity));
+                                               ctx->d_pool_info.ptr + q * n_tiles * wf_pool_info_bytes(), ctx->d_pool_list.ptr + q * 2u * (size_t)n_tiles));
                 if (s0 + group >= rp.spp)   // the last group's live-pool counts, for the next frame's split
-                    RWR_HIP_CHECK(hipMemcpyAsync(ctx->h_wf_live, ctx->d_wf_live.ptr + parity * 4u, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                    RWR_HIP_CHECK(hipMemcpyAsync(ctx->h_wf_live, wfq[q].counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, gs));
             }
         }
-        RWR_HIP_CHECK(launch_wf_resolve(stream, fp, tg, wf));
+        for (size_t q = 1; q < n_queues; q++) {
+            RWR_HIP_CHECK(hipEventRecord(ctx->wf_join[q], ctx->wf_streams[q]));
+            RWR_HIP_CHECK(hipStreamWaitEvent(stream, ctx->wf_join[q], 0));
+        }
+        RWR_HIP_CHECK(launch_wf_resolve(stream, fp, tg, wfq[0]));
         ctx->wf_fix_clean = true;   // (the resolve zeroes what it reads; rows outside the band were never touched)
         ctx->last_spp = rp.spp;
         ctx->last_segments = n_tiles;

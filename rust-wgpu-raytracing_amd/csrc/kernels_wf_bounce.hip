@@ -54,7 +54,7 @@ constexpr uint32_t kWfTraceGroups = 2048;  // workgroups of a trace launch (pers
 // Fewer packet pools than `min_packet_pools` (default 128, BvhDevice) in a launch group: the per-lane kernel takes them
 // (a packet is one long chain of dependent scalar loads; a handful of them on an otherwise idle chip take longer
 // than everything else in the frame).
-// device counters of one launch group (two sets, used alternately): pools of each class, work items handed out
+// device counters of one launch group (one set per ray queue, WfBuffers::counters): pools of each class, work items handed out
 enum { kLivePackets = 0, kLiveLane = 1, kWorkPackets = 2, kWorkLane = 3, kCountersPerParity = 4 };
 
 // float -> uint32 key whose unsigned order is the float order
@@ -101,7 +101,6 @@ k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict_
     uint16_t *s_bins = reinterpret_cast<uint16_t *>(s_dyn);   // direction bin of every slot (0xffff: no ray), then the sorted list: 2 x 2 B x sample_count x 512
     const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t n_masks = sample_count * 8u, n_slots = sample_count * kWfTilePixels;
-    if (tile == 0u && tid < (uint32_t)kCountersPerParity) counters[(parity ^ 1u) * kCountersPerParity + tid] = 0u;   // the next launch group's
     if (tid == 0u) sh.total = 0u;
     if (tid < 3u) { sh.lo[tid] = 0xffffffffu; sh.hi[tid] = 0u; }
     __syncthreads();
@@ -635,10 +634,11 @@ k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const
 
 hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                             const BvhDevice &bvh, const float4 *tex, const WfBuffers &wf, uint32_t n_tiles,
-                            uint32_t sample_count, uint32_t packet_min_rays, void *pool_info, uint32_t *counters,
-                            uint32_t *pool_list, uint32_t parity)
+                            uint32_t sample_count, uint32_t packet_min_rays, void *pool_info, uint32_t *pool_list)
 {
     if (n_tiles == 0 || sample_count == 0) return hipSuccess;
+    uint32_t *counters = wf.counters;   // this queue's set, zeroed by the primary stage that filled the queue
+    const uint32_t parity = 0u;
     PoolInfo *info = static_cast<PoolInfo *>(pool_info);
     // well-filled, compact pools: packet traversal (its one stack is a VGPR of 64 entries)
     const bool packets = bvh.stack_depth <= 64u && packet_min_rays <= sample_count * kWfTilePixels && bvh.packet_extent > 0.0f;

@@ -188,6 +188,8 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
     // z_split workgroups share a tile's samples (sample z, z + z_split, ...): on a frame that shows a small mesh a wave
     // would otherwise trace all the group's samples one after the other while most of the chip idles
     const uint32_t z = blockIdx.z;
+    // the bounce stage's counters for this queue start from zero (nothing reads them before this kernel has ended)
+    if (wf.counters && (blockIdx.x | blockIdx.y | z) == 0u && threadIdx.x < 4u) wf.counters[threadIdx.x] = 0u;
 
     // A tile no face and no sphere can be seen through (conservative bounds: nothing any jittered ray of its pixels could
     // hit) has nothing to trace in any sample: its pixels keep the clear values.  On a frame that shows a small mesh
@@ -381,7 +383,7 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
         const unsigned long long fa1 = (unsigned long long)hits1 * (unsigned long long)(2.0f * kWfFixedScale);
         const unsigned long long r0 = (unsigned long long)fr0 << 4, g0 = (unsigned long long)fg0 << 4, b0 = (unsigned long long)fb0 << 4;
         const unsigned long long r1 = (unsigned long long)fr1 << 4, g1 = (unsigned long long)fg1 << 4, b1 = (unsigned long long)fb1 << 4;
-        if (z_split == 1u) {
+        if (z_split == 1u && !wf.shared_planes) {
             wf.fix[pix0] += r0; wf.fix[plane + pix0] += g0; wf.fix[2u * plane + pix0] += b0; wf.fix[3u * plane + pix0] += fa0;
             if (in1) { wf.fix[pix0 + 1u] += r1; wf.fix[plane + pix0 + 1u] += g1; wf.fix[2u * plane + pix0 + 1u] += b1; wf.fix[3u * plane + pix0 + 1u] += fa1; }
         } else {

@@ -210,6 +210,8 @@ struct WfBuffers {
     uint32_t group;                // samples per launch group this frame
     uint32_t tiles_x;
     unsigned long long *dbg;       // optional (RWR_WF_STATS=1): {packet pools, their rays, per-lane pools, their rays}
+    uint32_t *counters;            // this queue's four counters of the bounce stage (kernels_wf_bounce.hip); null without a bounce
+    uint32_t shared_planes;        // another launch group may be adding to `fix` at the same time: atomics only
 };
 struct BvhNode4;
 struct BvhDevice {
@@ -229,8 +231,7 @@ hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriReco
                              const WfBuffers &wf, uint32_t sample_begin, uint32_t sample_count, uint32_t z_split);
 hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                             const BvhDevice &bvh, const float4 *tex, const WfBuffers &wf,
-                            uint32_t n_tiles, uint32_t sample_count, uint32_t packet_min_rays, void *pool_info, uint32_t *counters,
-                            uint32_t *pool_list, uint32_t parity);
+                            uint32_t n_tiles, uint32_t sample_count, uint32_t packet_min_rays, void *pool_info, uint32_t *pool_list);
 size_t wf_pool_info_bytes();
 hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                               const BvhDevice &bvh, const float4 *tex, const Targets &tg);
