@@ -173,10 +173,13 @@ k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict_
         }
     }
     __syncthreads();
-    {   // exclusive prefix over the 512 bins: two bins per thread, shuffle scan inside a wave, four wave totals through LDS
-        static_assert(kWfDirBins == 512u, "two bins per thread of a 256-thread workgroup");
-        const uint32_t c0 = sh.hist[2u * tid], c1 = sh.hist[2u * tid + 1u];
-        uint32_t incl = c0 + c1;
+    {   // exclusive prefix over the bins: kPer consecutive bins per thread, shuffle scan inside a wave, four wave totals through LDS
+        constexpr uint32_t kPer = kWfDirBins / 256u;
+        static_assert(kWfDirBins % 2048u == 0u || kWfDirBins == 512u, "whole bins per thread, an octant starts at a thread's first bin");
+        uint32_t c[kPer], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) { c[k] = sh.hist[kPer * tid + k]; sum += c[k]; }
+        uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
@@ -184,11 +187,11 @@ k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict_
         }
         if ((tid & 63u) == 63u) sh.wave_sum[tid >> 6] = incl;
         __syncthreads();
-        uint32_t before = incl - (c0 + c1);
+        uint32_t before = incl - sum;
         for (uint32_t w = 0; w < (tid >> 6); w++) before += sh.wave_sum[w];
-        sh.offs[2u * tid] = before;
-        sh.offs[2u * tid + 1u] = before + c0;
-        if ((tid & 31u) == 0u) info[tile].oct_begin[tid >> 5] = before;   // bin 64 o = 2 * (32 o): where octant o begins
+        if ((tid & 31u) == 0u) info[tile].oct_begin[tid >> 5] = before;   // octant o begins at bin (kWfDirBins / 8) o = kPer * (32 o)
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) { sh.offs[kPer * tid + k] = before; before += c[k]; }
     }
     if (tid == 0u) {
         info[tile].oct_begin[8] = n_rays;

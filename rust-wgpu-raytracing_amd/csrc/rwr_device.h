@@ -438,17 +438,20 @@ RWR_DEV f3 bounce_direction(f3 n, uint32_t pixel, uint32_t sample, uint32_t seed
 }
 
 // Wavefront integrator: the key a tile's ray pool is sorted by (kernels_wf_primary.hip stores it, kernels_wf_bounce.hip sorts).
-// Direction bin: 3 bits of octant (Gray-coded so that neighbours share two signs) and 6 bits of position inside
-// the octant's triangle of the octahedral map (Morton order of an 8x8 grid).
+// Direction bin: 3 bits of octant (Gray-coded so that neighbours share two signs) and 2 x kWfDirCellBits bits of position
+// inside the octant's triangle of the octahedral map (Morton order of a 2^bits x 2^bits grid).
 RWR_DEV uint32_t wf_direction_bin(f3 D)
 {
     const uint32_t sx = __float_as_uint(D.x) >> 31, sy = __float_as_uint(D.y) >> 31, sz = __float_as_uint(D.z) >> 31;
     const uint32_t oct = sz * 4u + (sy ^ sz) * 2u + (sx ^ sy);  // reflected Gray code of (sz, sy, sx)
     const float ax = fabsf(D.x), ay = fabsf(D.y), az = fabsf(D.z);
     const float inv = __builtin_amdgcn_rcpf(ax + ay + az + 1e-30f);
-    const uint32_t iu = min(7u, (uint32_t)(ax * inv * 8.0f)), iv = min(7u, (uint32_t)(ay * inv * 8.0f));
-    const uint32_t mu = (iu & 1u) | ((iu & 2u) << 1) | ((iu & 4u) << 2), mv = (iv & 1u) | ((iv & 2u) << 1) | ((iv & 4u) << 2);
-    return oct * 64u + (mu | (mv << 1));
+    constexpr uint32_t kCells = 1u << kWfDirCellBits;
+    const uint32_t iu = min(kCells - 1u, (uint32_t)(ax * inv * (float)kCells)), iv = min(kCells - 1u, (uint32_t)(ay * inv * (float)kCells));
+    uint32_t mu = 0, mv = 0;   // Morton order inside the octant
+#pragma unroll
+    for (uint32_t b = 0; b < kWfDirCellBits; b++) { mu |= (iu & (1u << b)) << b; mv |= (iv & (1u << b)) << b; }
+    return oct * (kCells * kCells) + (mu | (mv << 1));
 }
 
 // Wavefront ray records (rwr_internal.h WfBuffers::rays): the throughput's three channels as unorm16 in the two w components.

@@ -197,7 +197,11 @@ hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, co
 constexpr uint32_t kWfTileW = 64, kWfTileH = 8, kWfTilePixels = kWfTileW * kWfTileH;
 constexpr uint32_t kWfMaxGroup = 32;          // samples per launch group (LDS of the bounce stage is sized for it)
 constexpr float kWfFixedScale = 67108864.0f;  // 2^26: a term < 64, thousands of them < 2^64
-constexpr uint32_t kWfDirBins = 512;          // 8 octants x 8x8 cells of the octahedral map
+#ifndef RWR_WF_CELL_BITS
+#define RWR_WF_CELL_BITS 3
+#endif
+constexpr uint32_t kWfDirCellBits = RWR_WF_CELL_BITS;                 // cells per side of an octant of the octahedral map, log2
+constexpr uint32_t kWfDirBins = 8u << (2u * kWfDirCellBits);   // 8 octants x 8x8 cells (16x16 measured slower: the sort loses more than the packets gain)
 struct WfBuffers {
     unsigned long long *fix;       // 4 planes of W*H: the frame's radiance sums as 2^-26 FIXED POINT — red, green, blue of
                                    // E(h0) + albedo(h0) * E(h1) over all samples, and alpha (2 per primary hit).  Integer sums are
