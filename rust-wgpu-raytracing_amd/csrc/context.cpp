@@ -138,6 +138,7 @@ struct rwr_context {
     DeviceBuffer<uint8_t> d_pool_info;
     DeviceBuffer<uint32_t> d_wf_live;            // device counters of the bounce stage, a set of four per ray queue
     DeviceBuffer<uint32_t> d_pool_list;          // live pools by class, 2 x tiles
+    DeviceBuffer<uint32_t> d_wf_tiles;           // frames that show little: live tile list, per-tile live pieces, the count (k_wf_classify)
     DeviceBuffer<unsigned long long> d_wf_dbg;   // RWR_WF_STATS=1: pool classification counters, printed at destroy
     uint32_t wf_group = 32;         // samples per launch group; tunable: RWR_WF_GROUP (1..32)
     float wf_packet_fill = 0.25f;   // pools filled at least this much are traced as packets; tunable: RWR_WF_PACKET_FILL (> 1: never)
@@ -529,7 +530,7 @@ void rwr_ctx_destroy(rwr_context *ctx)
         if (ctx->wf_join[q]) { (void)hipEventDestroy(ctx->wf_join[q]); ctx->wf_join[q] = nullptr; }
     }
     if (ctx->wf_fork) { (void)hipEventDestroy(ctx->wf_fork); ctx->wf_fork = nullptr; }
-    ctx->d_rays.release(); if (ctx->h_wf_live) { (void)hipHostFree(ctx->h_wf_live); ctx->h_wf_live = nullptr; } ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wf_bins.release(); ctx->d_wave_total.release(); ctx->d_wf_fix.release(); ctx->d_pool_info.release(); ctx->d_wf_live.release(); ctx->d_pool_list.release(); for (auto &t : ctx->d_texs) t.release();
+    ctx->d_rays.release(); if (ctx->h_wf_live) { (void)hipHostFree(ctx->h_wf_live); ctx->h_wf_live = nullptr; } ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wf_bins.release(); ctx->d_wave_total.release(); ctx->d_wf_fix.release(); ctx->d_pool_info.release(); ctx->d_wf_live.release(); ctx->d_pool_list.release(); ctx->d_wf_tiles.release(); for (auto &t : ctx->d_texs) t.release();
     ctx->d_face_mat.release(); ctx->d_materials.release();
     for (FrameSlot &sl : ctx->slots) {
         sl.release_buffers();
@@ -1007,6 +1008,15 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         // queue q: its half of every per-group buffer and its set of four counters (the primary stage zeroes the set it
         // is about to fill).  With one queue the frame's sums are read-modify-written by the tile's only workgroup; with
         // two, a group's primary stage runs beside the other group's trace kernels and everybody adds atomically.
+        // A frame expected to show little (z_split > 1: the previous frame did) first lists the tiles anything can be seen
+        // through; the primary stage, the sort and the resolve then touch those alone.  Same frame either way.
+        uint32_t *live_list = nullptr, *live_count = nullptr, *tile_live = nullptr;
+        if (z_split > 1u && !(rp.flags & RWR_FLAG_NO_CULL)) {
+            RWR_HIP_CHECK(ctx->d_wf_tiles.ensure(2u * (size_t)n_tiles + 1u));
+            live_list = ctx->d_wf_tiles.ptr; tile_live = live_list + n_tiles; live_count = tile_live + n_tiles;
+            RWR_HIP_CHECK(hipMemsetAsync(live_count, 0, sizeof(uint32_t), stream));
+            RWR_HIP_CHECK(launch_wf_classify(stream, fp, sl.d_ftris.ptr, tg, tiles_x, live_list, live_count, tile_live));
+        }
         WfBuffers wfq[rwr_context::kWfMaxQueues];
         for (size_t q = 0; q < n_queues; q++) {
             const size_t h = q;
@@ -1016,7 +1026,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
                                ctx->d_wf_bins.ptr ? ctx->d_wf_bins.ptr + h * slots : nullptr,
                                ctx->d_wf_sorted.ptr ? ctx->d_wf_sorted.ptr + h * slots : nullptr,
                                ctx->d_wave_total.ptr, group, tiles_x, ctx->d_wf_dbg.ptr,
-                               rp.max_bounces ? ctx->d_wf_live.ptr + h * 4u : nullptr, overlap ? 1u : 0u};
+                               rp.max_bounces ? ctx->d_wf_live.ptr + h * 4u : nullptr, overlap ? 1u : 0u, live_list, live_count, tile_live};
         }
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u,
                             ctx->wf_packet_extent * ctx->bvh_leaf_extent, ctx->wf_min_packet_pools};

@@ -98,10 +98,19 @@ template <bool AUX>
 __global__ void __launch_bounds__(256)
 k_wf_resolve(const FrameParams p, const Targets tg, WfBuffers wf)
 {
-    const uint32_t n = p.width * (p.row_end - p.row_begin);
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t pixel = p.row_begin * p.width + i;
+    // a workgroup = 64 x 4 pixels: one row of 64 per wave, whole 512-byte pieces of every plane
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), ly = blockIdx.y * 4u + (threadIdx.x >> 6), y = p.row_begin + ly;
+    if (x >= p.width || y >= p.row_end) return;
+    const uint32_t pixel = y * p.width + x;
+    if (wf.tile_live) {   // a piece of a tile nothing can be seen through (k_wf_classify): its sums were never touched
+        const uint32_t live = wf.tile_live[(ly / kWfTileH) * wf.tiles_x + blockIdx.x];
+        const uint32_t piece = ((ly >> 2) & 1u) * 2u + ((threadIdx.x >> 5) & 1u);
+        if (!((live >> piece) & 1u)) {
+            reinterpret_cast<uint32_t *>(tg.color)[pixel] = 0u;
+            if (AUX) reinterpret_cast<float4 *>(tg.color_f32)[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            return;
+        }
+    }
     // the frame's fixed-point sums (2^-26 units; kernels_wf_primary.hip, kernels_wf_bounce.hip), read and left zeroed for
     // the next frame
     const size_t plane = (size_t)p.width * p.height;
@@ -116,8 +125,7 @@ k_wf_resolve(const FrameParams p, const Targets tg, WfBuffers wf)
 hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
-    const uint32_t n = fp.width * (fp.row_end - fp.row_begin);
-    const dim3 grid((n + 255u) / 256u);
+    const dim3 grid((fp.width + 63u) / 64u, (fp.row_end - fp.row_begin + 3u) / 4u);
     if (fp.flags & RWR_FLAG_AUX_OUTPUTS) hipLaunchKernelGGL((k_wf_resolve<true>), grid, dim3(256), 0, s, fp, tg, wf);
     else hipLaunchKernelGGL((k_wf_resolve<false>), grid, dim3(256), 0, s, fp, tg, wf);
     return hipGetLastError();

@@ -92,14 +92,11 @@ struct SortShared {
 // A pool is traced as PACKETS when it is well filled (min_fill rays) and its rays start close together compared
 // with the geometry (origins within bvh.packet_extent): then the rays of one direction bin really travel
 // together.  A tile that spans many small faces (a distant instance) is not such a pool.
-__global__ void __launch_bounds__(256)
-k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list,
-          uint32_t n_tiles, uint32_t parity, uint32_t sample_count, uint32_t min_fill, float packet_extent)
+RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, const WfBuffers &wf, PoolInfo *__restrict__ info,
+                       uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list, uint32_t n_tiles, uint32_t parity,
+                       uint32_t sample_count, uint32_t min_fill, float packet_extent)
 {
-    __shared__ SortShared sh;
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    uint16_t *s_bins = reinterpret_cast<uint16_t *>(s_dyn);   // direction bin of every slot (0xffff: no ray), then the sorted list: 2 x 2 B x sample_count x 512
-    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     const uint32_t n_masks = sample_count * 8u, n_slots = sample_count * kWfTilePixels;
     if (tid == 0u) sh.total = 0u;
     if (tid < 3u) { sh.lo[tid] = 0xffffffffu; sh.hi[tid] = 0u; }
@@ -217,6 +214,28 @@ k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict_
     uint4 *__restrict__ out = reinterpret_cast<uint4 *>(wf.sorted + pool_base);   // pool_base is a multiple of 512
     const uint4 *src = reinterpret_cast<const uint4 *>(s_sorted);
     for (uint32_t i = tid; i < (n_rays + 7u) / 8u; i += 256u) out[i] = src[i];
+}
+
+// One workgroup per pool — or, on a frame that shows little, workgroups striding over the live tiles of k_wf_classify's list
+// (the other tiles emitted nothing and nobody looks at their pools).
+template <bool LIST>
+__global__ void __launch_bounds__(256)
+k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list,
+          uint32_t n_tiles, uint32_t parity, uint32_t sample_count, uint32_t min_fill, float packet_extent)
+{
+    __shared__ SortShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    uint16_t *s_bins = reinterpret_cast<uint16_t *>(s_dyn);   // direction bin of every slot (0xffff: no ray), then the sorted list: 2 x 2 B x sample_count x 512
+    if (!LIST) {
+        sort_pool(sh, s_bins, blockIdx.x, wf, info, counters, pool_list, n_tiles, parity, sample_count, min_fill, packet_extent);
+        return;
+    }
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)*wf.live_count);
+    for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
+        const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)wf.live_list[t]);
+        sort_pool(sh, s_bins, tile, wf, info, counters, pool_list, n_tiles, parity, sample_count, min_fill, packet_extent);
+        __syncthreads();   // (the next pool reuses the LDS)
+    }
 }
 
 // What a trace workgroup keeps in LDS: fixed-point sums of albedo * E(h1) per pixel of the tile.
@@ -645,8 +664,13 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
     PoolInfo *info = static_cast<PoolInfo *>(pool_info);
     // well-filled, compact pools: packet traversal (its one stack is a VGPR of 64 entries)
     const bool packets = bvh.stack_depth <= 64u && packet_min_rays <= sample_count * kWfTilePixels && bvh.packet_extent > 0.0f;
-    hipLaunchKernelGGL(k_wf_sort, dim3(n_tiles), dim3(256), 2u * (size_t)sample_count * kWfTilePixels * sizeof(uint16_t), s, wf, info, counters, pool_list, n_tiles, parity, sample_count,
-                       packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);
+    const size_t sort_lds = 2u * (size_t)sample_count * kWfTilePixels * sizeof(uint16_t);
+    if (wf.live_list)
+        hipLaunchKernelGGL(k_wf_sort<true>, dim3(std::min(n_tiles, 2048u)), dim3(256), sort_lds, s, wf, info, counters, pool_list, n_tiles, parity,
+                           sample_count, packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);
+    else
+        hipLaunchKernelGGL(k_wf_sort<false>, dim3(n_tiles), dim3(256), sort_lds, s, wf, info, counters, pool_list, n_tiles, parity,
+                           sample_count, packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);
     const dim3 grid(std::min(kWfTraceGroups, n_tiles * kWfMaxSplit));
     const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0;
     if (packets) {

@@ -24,6 +24,7 @@
 
 #include "rwr_primary.h"
 #include "rwr_shade_p2.h"
+#include "rwr_wf_cull.h"
 
 namespace rwr {
 
@@ -125,7 +126,7 @@ RWR_DEV v3 bounce_direction_pair(v3 n, u2 base, i2 want)
 #ifndef RWR_WF_OCC
 #define RWR_WF_OCC 4
 #endif
-template <bool AUX, bool CULL, bool NMAP>
+template <bool AUX, bool CULL, bool NMAP, bool LIST = false>
 __global__ void __launch_bounds__(256, (AUX || NMAP) ? 3 : RWR_WF_OCC)
 k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_begin, uint32_t bins_enabled,
              int32_t mesh_x0, int32_t mesh_y0, int32_t mesh_x1, int32_t mesh_y1, uint32_t sample_begin, uint32_t sample_count,
@@ -133,49 +134,41 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
              const float4 *__restrict__ tex, const Targets tg, const WfBuffers wf)
 {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t blk_x0 = blockIdx.x * kWfTileW;
+    // the bounce stage's counters for this queue start from zero (nothing reads them before this kernel has ended)
+    if (wf.counters && (blockIdx.x | blockIdx.y | blockIdx.z) == 0u && threadIdx.x < 4u) wf.counters[threadIdx.x] = 0u;
+    // which tile, which share of its samples: the launch grid's (x, y, z) — or, on a frame that shows little, item after item
+    // of (live tile of k_wf_classify's list) x (share), so that no workgroup is spent on finding its tile empty
+    uint32_t bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+    uint32_t item = blockIdx.x, n_items = 0u;
+    if (LIST) n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)*wf.live_count) * z_split;
+    do {
+    if (LIST) {
+        if (item >= n_items) break;
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)wf.live_list[item / z_split]);
+        z = item % z_split;
+        by = t / wf.tiles_x;
+        bx = t - by * wf.tiles_x;
+        item += gridDim.x;
+    }
+    const uint32_t blk_x0 = bx * kWfTileW;
     const uint32_t tile_x0 = blk_x0 + (wave & 1u) * 32u;
-    const uint32_t tile_y0 = row_begin + blockIdx.y * kWfTileH + (wave >> 1) * 4u;
+    const uint32_t tile_y0 = row_begin + by * kWfTileH + (wave >> 1) * 4u;
     const uint32_t px0 = tile_x0 + 2u * (lane & 15u), py = tile_y0 + (lane >> 4);
     constexpr float kTileWf = 32.0f, kTileHf = 4.0f;
     const bool in0 = py < p.row_end && px0 < p.width, in1 = in0 && (px0 + 1u < p.width);
     const uint32_t pix0 = py * p.width + px0;  // GLOBAL pixel index: RNG key and accumulator slot (< 2^30, rwr_resize)
-    const uint32_t tile = blockIdx.y * wf.tiles_x + blockIdx.x;
+    const uint32_t tile = by * wf.tiles_x + bx;
 
-    // source of candidate faces: the whole scene, or this tile's screen bin (shared by all samples of the frame)
-    uint32_t n_src = n_tris;
-    const uint32_t *__restrict__ src = nullptr;
-    if (CULL && bins_enabled) {
-        const uint32_t bin = ((tile_y0 - row_begin) / kBinH) * p.bins.bins_x + blk_x0 / kBinW;
-        const uint32_t off = p.bins.offsets[bin];
-        if (off != kBinNoList) {   // (kBinNoList: this frame's lists did not fit; walk the whole scene)
-            n_src = p.bins.counts[bin];
-            src = p.bins.lists + off;
-        }
-    }
-    n_src = __builtin_amdgcn_readfirstlane(n_src);
-    if (CULL) {  // the tile lies outside the screen rectangle of the whole mesh
-        const int32_t wu = __builtin_amdgcn_readfirstlane((int32_t)wave);
-        const int32_t sx0 = (int32_t)blk_x0 + (wu & 1) * 32, sy0 = (int32_t)(row_begin + blockIdx.y * kWfTileH) + (wu >> 1) * 4;
-        if (sx0 + 32 < mesh_x0 || sx0 > mesh_x1 || sy0 + 4 < mesh_y0 || sy0 > mesh_y1) n_src = 0u;
-    }
+    // candidate faces of this wave's tile: rwr_wf_cull.h (shared with k_wf_classify)
+    const WfWaveCull wc = wf_wave_cull<CULL>(ftris, n_tris, row_begin, bins_enabled, mesh_x0, mesh_y0, mesh_x1, mesh_y1, p.bins, blk_x0,
+                                             row_begin + by * kWfTileH, wave, lane);
+    const uint32_t n_src = wc.n_src;
+    const uint32_t *__restrict__ src = wc.src;
     const float tx0 = (float)tile_x0, ty0 = (float)tile_y0;
     const TileRect tile_rect = {tx0, ty0, tx0 + kTileWf, ty0 + kTileHf};
-    // Jitter keeps a sample inside its pixel, so the tile's candidate faces are the same for every sample: up to 128
-    // source faces are culled once (two ballots, the face of each bit in a VGPR); longer lists are re-culled per sample.
-    const bool cached = n_src <= 128u;
-    unsigned long long cm0 = 0ull, cm1 = 0ull;
-    uint32_t cf0 = lane, cf1 = 64u + lane;
-    if (cached) {
-        bool keep = lane < n_src;
-        cf0 = (keep && src) ? src[lane] : lane;
-        if (CULL && keep) keep = !rect_culls(ftris[cf0], tile_rect);
-        cm0 = __ballot(keep);
-        keep = 64u + lane < n_src;
-        cf1 = (keep && src) ? src[64u + lane] : 64u + lane;
-        if (CULL && keep) keep = !rect_culls(ftris[cf1], tile_rect);
-        cm1 = __ballot(keep);
-    }
+    const bool cached = wc.cached;
+    const unsigned long long cm0 = wc.cm0, cm1 = wc.cm1;
+    const uint32_t cf0 = wc.cf0, cf1 = wc.cf1;
     const float fw = (float)p.width, fh = (float)p.height;
     const float rw = refined_rcp(fw), rh = refined_rcp(fh);
     const f3 O = ld3(p.cam.origin);
@@ -187,19 +180,11 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
     uint32_t emitted = 0;  // rays this wave emitted in this launch (wave-uniform)
     // z_split workgroups share a tile's samples (sample z, z + z_split, ...): on a frame that shows a small mesh a wave
     // would otherwise trace all the group's samples one after the other while most of the chip idles
-    const uint32_t z = blockIdx.z;
-    // the bounce stage's counters for this queue start from zero (nothing reads them before this kernel has ended)
-    if (wf.counters && (blockIdx.x | blockIdx.y | z) == 0u && threadIdx.x < 4u) wf.counters[threadIdx.x] = 0u;
 
     // A tile no face and no sphere can be seen through (conservative bounds: nothing any jittered ray of its pixels could
     // hit) has nothing to trace in any sample: its pixels keep the clear values.  On a frame that shows a small mesh
     // that is most tiles.
-    bool empty_tile = CULL && (n_src == 0u || (cached && (cm0 | cm1) == 0ull));
-    if (empty_tile)
-        for (uint32_t s = 0; s < p.n_spheres; s++)
-            if (!((tx0 + kTileWf < p.sphere_rect[s][0]) || (tx0 > p.sphere_rect[s][2]) || (ty0 + kTileHf < p.sphere_rect[s][1]) ||
-                  (ty0 > p.sphere_rect[s][3])))
-                empty_tile = false;
+    const bool empty_tile = wf_wave_empty<CULL>(wc, p, tx0, ty0);
     if (empty_tile && sample_begin == 0u && z == 0u && in0) {   // sample 0's planes
         tg.depth[pix0] = 0.0f;
         if (AUX) { tg.obj_id[pix0] = -1; tg.hit_t[pix0] = 0.0f; }
@@ -383,7 +368,7 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
         const unsigned long long fa1 = (unsigned long long)hits1 * (unsigned long long)(2.0f * kWfFixedScale);
         const unsigned long long r0 = (unsigned long long)fr0 << 4, g0 = (unsigned long long)fg0 << 4, b0 = (unsigned long long)fb0 << 4;
         const unsigned long long r1 = (unsigned long long)fr1 << 4, g1 = (unsigned long long)fg1 << 4, b1 = (unsigned long long)fb1 << 4;
-        if (z_split == 1u && !wf.shared_planes) {
+        if (!LIST && z_split == 1u && !wf.shared_planes) {
             wf.fix[pix0] += r0; wf.fix[plane + pix0] += g0; wf.fix[2u * plane + pix0] += b0; wf.fix[3u * plane + pix0] += fa0;
             if (in1) { wf.fix[pix0 + 1u] += r1; wf.fix[plane + pix0 + 1u] += g1; wf.fix[2u * plane + pix0 + 1u] += b1; wf.fix[3u * plane + pix0 + 1u] += fa1; }
         } else {
@@ -392,6 +377,7 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
         }
     }
     if (lane == 0u && emitted) atomicAdd(wf.wave_total + tile * 4u + wave, emitted);   // (zeroed when the frame starts)
+    } while (LIST);
 }
 
 hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
@@ -407,7 +393,13 @@ hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriReco
                     sample_begin, sample_count, z_split, fp, tris, shade, tex, tg, wf
     const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0;
 #define RWR_WF_LAUNCH(A, C, N) hipLaunchKernelGGL((k_wf_primary<A, C, N>), grid, block, 0, s, RWR_WF_ARGS)
-    if (nmap) {
+    if (wf.live_list && do_cull) {   // item after item of (live tile) x (share of its samples)
+        const dim3 lgrid(std::min(grid.x * grid.y * z_split, 4096u));
+#define RWR_WF_LAUNCH_LIST(A, N) hipLaunchKernelGGL((k_wf_primary<A, true, N, true>), lgrid, block, 0, s, RWR_WF_ARGS)
+        if (nmap) { if (aux) RWR_WF_LAUNCH_LIST(true, true); else RWR_WF_LAUNCH_LIST(false, true); }
+        else { if (aux) RWR_WF_LAUNCH_LIST(true, false); else RWR_WF_LAUNCH_LIST(false, false); }
+#undef RWR_WF_LAUNCH_LIST
+    } else if (nmap) {
         if (aux && do_cull) RWR_WF_LAUNCH(true, true, true);
         else if (aux) RWR_WF_LAUNCH(true, false, true);
         else if (do_cull) RWR_WF_LAUNCH(false, true, true);
@@ -420,6 +412,58 @@ hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriReco
     }
 #undef RWR_WF_LAUNCH
 #undef RWR_WF_ARGS
+    return hipGetLastError();
+}
+
+// Frames that show little (a small mesh on an empty screen): which tiles can anything be seen through?  One workgroup per
+// 64x8-pixel tile, its four waves reaching the verdict the primary stage's waves would reach (rwr_wf_cull.h).  Tiles with a
+// live wave are listed (any order); a wave that sees nothing gives its pixels the clear values of sample 0's planes here,
+// and the resolve step skips its pixels' sums (nothing is ever added to them).
+template <bool AUX>
+__global__ void __launch_bounds__(256)
+k_wf_classify(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_begin, uint32_t bins_enabled, int32_t mesh_x0,
+              int32_t mesh_y0, int32_t mesh_x1, int32_t mesh_y1, const FrameParams p, const Targets tg, uint32_t tiles_x,
+              uint32_t *__restrict__ live_list, uint32_t *__restrict__ live_count, uint32_t *__restrict__ tile_live)
+{
+    __shared__ uint32_t s_live;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (threadIdx.x == 0u) s_live = 0u;
+    __syncthreads();
+    const uint32_t blk_x0 = blockIdx.x * kWfTileW, blk_y0 = row_begin + blockIdx.y * kWfTileH;
+    const uint32_t tile_x0 = blk_x0 + (wave & 1u) * 32u, tile_y0 = blk_y0 + (wave >> 1) * 4u;
+    const WfWaveCull wc = wf_wave_cull<true>(ftris, n_tris, row_begin, bins_enabled, mesh_x0, mesh_y0, mesh_x1, mesh_y1, p.bins, blk_x0,
+                                             blk_y0, wave, lane);
+    if (wf_wave_empty<true>(wc, p, (float)tile_x0, (float)tile_y0)) {
+        const uint32_t px0 = tile_x0 + 2u * (lane & 15u), py = tile_y0 + (lane >> 4);
+        if (py < p.row_end && px0 < p.width) {
+            const uint32_t pix0 = py * p.width + px0;
+            tg.depth[pix0] = 0.0f;
+            if (AUX) { tg.obj_id[pix0] = -1; tg.hit_t[pix0] = 0.0f; }
+            if (px0 + 1u < p.width) {
+                tg.depth[pix0 + 1u] = 0.0f;
+                if (AUX) { tg.obj_id[pix0 + 1u] = -1; tg.hit_t[pix0 + 1u] = 0.0f; }
+            }
+        }
+    } else if (lane == 0u) {
+        atomicOr(&s_live, 1u << wave);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const uint32_t tile = blockIdx.y * tiles_x + blockIdx.x, live = s_live;
+        tile_live[tile] = live;
+        if (live) live_list[atomicAdd(live_count, 1u)] = tile;
+    }
+}
+
+hipError_t launch_wf_classify(hipStream_t s, const FrameParams &fp, const FrameTri *ftris, const Targets &tg, uint32_t tiles_x,
+                              uint32_t *live_list, uint32_t *live_count, uint32_t *tile_live)
+{
+    if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
+    const dim3 grid(tiles_x, (fp.row_end - fp.row_begin + kWfTileH - 1u) / kWfTileH);
+#define RWR_WF_CLASSIFY(A) hipLaunchKernelGGL((k_wf_classify<A>), grid, dim3(256), 0, s, ftris, fp.n_tris, fp.row_begin, fp.bins.enabled, \
+        fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tg, tiles_x, live_list, live_count, tile_live)
+    if (fp.flags & RWR_FLAG_AUX_OUTPUTS) RWR_WF_CLASSIFY(true); else RWR_WF_CLASSIFY(false);
+#undef RWR_WF_CLASSIFY
     return hipGetLastError();
 }
 

@@ -216,6 +216,11 @@ struct WfBuffers {
     unsigned long long *dbg;       // optional (RWR_WF_STATS=1): {packet pools, their rays, per-lane pools, their rays}
     uint32_t *counters;            // this queue's four counters of the bounce stage (kernels_wf_bounce.hip); null without a bounce
     uint32_t shared_planes;        // another launch group may be adding to `fix` at the same time: atomics only
+    // frames that show little (k_wf_classify ran): the tiles something can be seen through, how many, and per tile which of its
+    // four waves' 32x4-pixel pieces; null otherwise (every tile is looked at)
+    const uint32_t *live_list;
+    const uint32_t *live_count;
+    const uint32_t *tile_live;
 };
 struct BvhNode4;
 struct BvhDevice {
@@ -233,6 +238,9 @@ hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriReco
 hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                              const FrameTri *ftris, const float4 *tex, const Targets &tg,
                              const WfBuffers &wf, uint32_t sample_begin, uint32_t sample_count, uint32_t z_split);
+// once per frame, ahead of the primary stage, when the frame is expected to show little: fills live_list / live_count / tile_live
+hipError_t launch_wf_classify(hipStream_t s, const FrameParams &fp, const FrameTri *ftris, const Targets &tg, uint32_t tiles_x,
+                              uint32_t *live_list, uint32_t *live_count, uint32_t *tile_live);
 hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                             const BvhDevice &bvh, const float4 *tex, const WfBuffers &wf,
                             uint32_t n_tiles, uint32_t sample_count, uint32_t packet_min_rays, void *pool_info, uint32_t *pool_list);
