@@ -910,13 +910,13 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
             capacity = std::min<uint64_t>(capacity, 0xfffffff0ull);
             if (capacity > sl.d_bin_lists.count) RWR_HIP_CHECK(hipStreamSynchronize(stream));   // the old buffer may still be read
             RWR_HIP_CHECK(sl.d_bin_lists.ensure((size_t)capacity));
-            RWR_HIP_CHECK(sl.d_bin_counts.ensure(n_bins));
+            RWR_HIP_CHECK(sl.d_bin_counts.ensure(5u * (size_t)n_bins));   // four wave counts per bin, then the bins' own counts (launch_bin_faces)
             RWR_HIP_CHECK(sl.d_bin_offsets.ensure(n_bins));
             RWR_HIP_CHECK(sl.d_bin_total.ensure(1));
             RWR_HIP_CHECK(launch_bin_faces(stream, sl.d_ftris.ptr, ctx->n_tris, row_begin, sl.d_bin_lists.ptr, sl.d_bin_counts.ptr,
                                            sl.d_bin_offsets.ptr, sl.d_bin_total.ptr, bins_x, bins_y, (uint32_t)sl.d_bin_lists.count));
             RWR_HIP_CHECK(hipMemcpyAsync(sl.h_bin_total, sl.d_bin_total.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            fp.bins = BinGrid{sl.d_bin_lists.ptr, sl.d_bin_counts.ptr, sl.d_bin_offsets.ptr, bins_x, bins_y, (uint32_t)sl.d_bin_lists.count, 1u};
+            fp.bins = BinGrid{sl.d_bin_lists.ptr, sl.d_bin_counts.ptr + 4u * (size_t)n_bins, sl.d_bin_offsets.ptr, bins_x, bins_y, (uint32_t)sl.d_bin_lists.count, 1u};
         }
     }
     const bool time_this = ctx->timing_every && (ctx->timing_calls++ % ctx->timing_every == 0) && ctx->timing_pairs < 256;

@@ -192,54 +192,55 @@ hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const rwr_cam
 
 // ---------------------------------------------------------------------------
 // Per-frame screen binning, sized by a count pass: k_bin_faces<false> counts, per 64x32-pixel bin, the faces its
-// rectangle cannot reject (one workgroup per bin walks all faces 256 at a time); k_bin_scan turns the counts into
-// list offsets (exclusive scan) and reports the total; k_bin_faces<true> walks the faces again and writes every
-// bin's ascending list at its offset (same ballot + prefix compaction as the render kernels' block level, so lists
-// stay in face order and the lowest-index tie rule survives).  When the total exceeds the buffer's capacity the
-// scan marks every bin kBinNoList — the render kernels then walk the whole scene for this frame, the same
-// pixels — and the context allocates more for the next frames.
+// rectangle cannot reject; k_bin_scan turns the counts into list offsets (exclusive scan) and reports the total;
+// k_bin_faces<true> walks the faces again and writes every bin's ascending list at its offset.  One workgroup per bin;
+// each of its four waves owns one contiguous quarter of the faces and counts (then fills) it by ballot + prefix popcount
+// with no barrier and nothing shared — the count pass leaves one count per (bin, wave), so the fill pass knows where every
+// wave's part of the list begins.  Lists stay in face order: the lowest-index tie rule survives.  When the total exceeds
+// the buffer's capacity the scan marks every bin kBinNoList — the render kernels then walk the whole scene for this
+// frame, the same pixels — and the context allocates more for the next frames.
 template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_bin_faces(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *__restrict__ lists,
-            uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets, uint32_t bins_x)
+            uint32_t *__restrict__ counts4, const uint32_t *__restrict__ offsets, uint32_t bins_x)
 {
-    __shared__ uint32_t s_cnt[4];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     const uint32_t bin = blockIdx.y * bins_x + blockIdx.x;
+    const uint32_t quarter = ((n_tris + 255u) / 256u) * 64u;
+    const uint32_t begin = wave * quarter, end = min(n_tris, begin + quarter);
     uint32_t *__restrict__ out = nullptr;
     if (FILL) {
         const uint32_t off = offsets[bin];
         if (off == kBinNoList) return;   // uniform
-        out = lists + off;
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; w++) before += counts4[bin * 4u + w];
+        out = lists + off + before;
     }
     const float x0 = (float)(blockIdx.x * kBinW), y0 = (float)(row_begin + blockIdx.y * kBinH);
     const TileRect rect = {x0, y0, x0 + (float)kBinW, y0 + (float)kBinH};
     uint32_t written = 0;
-    for (uint32_t base = 0; base < n_tris; base += 256u) {
-        const uint32_t j = base + threadIdx.x;
-        bool keep = j < n_tris;
-        if (keep) keep = !rect_culls(ftris[j], rect);
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t off = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < 4; w++) {
-            const uint32_t c = s_cnt[w];
-            off += (w < wave) ? c : 0u;
-            total += c;
-        }
-        if (FILL && keep) out[written + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;  // within the counted size
-        written += total;
-        __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t base = begin; base < end; base += 128u) {   // two records per lane in flight before the first test
+        const uint32_t j0 = base + lane, j1 = j0 + 64u;
+        const bool in0 = j0 < end, in1 = j1 < end;
+        FrameTri t0 = {}, t1 = {};
+        if (in0) t0 = ftris[j0];
+        if (in1) t1 = ftris[j1];
+        const bool keep0 = in0 && !rect_culls(t0, rect), keep1 = in1 && !rect_culls(t1, rect);
+        const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
+        const uint32_t c0 = (uint32_t)__popcll(m0);
+        if (FILL && keep0) out[written + (uint32_t)__popcll(m0 & below)] = j0;  // within the counted size
+        if (FILL && keep1) out[written + c0 + (uint32_t)__popcll(m1 & below)] = j1;
+        written += c0 + (uint32_t)__popcll(m1);
     }
-    if (!FILL && threadIdx.x == 0) counts[bin] = written;
+    if (!FILL && lane == 0u) counts4[bin * 4u + wave] = written;
 }
 
-// One workgroup: offsets[b] = sum of counts[0..b), *total = the sum; everything kBinNoList when it exceeds capacity.
+// One workgroup: counts[b] = the bin's four wave counts, offsets[b] = sum of counts[0..b), *total = the sum; everything
+// kBinNoList when it exceeds capacity.
 __global__ void __launch_bounds__(1024)
-k_bin_scan(const uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets, uint32_t *__restrict__ total_out, uint32_t n_bins,
-           uint32_t capacity)
+k_bin_scan(const uint32_t *__restrict__ counts4, uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets,
+           uint32_t *__restrict__ total_out, uint32_t n_bins, uint32_t capacity)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
@@ -248,7 +249,12 @@ k_bin_scan(const uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets, 
     __syncthreads();
     for (uint32_t base = 0; base < n_bins; base += 1024u) {
         const uint32_t b = base + tid;
-        const uint32_t c = b < n_bins ? counts[b] : 0u;
+        uint32_t c = 0u;
+        if (b < n_bins) {   // a bin's count = its four waves' counts (k_bin_faces<false>)
+            const uint4 c4 = reinterpret_cast<const uint4 *>(counts4)[b];
+            c = c4.x + c4.y + c4.z + c4.w;
+            counts[b] = c;
+        }
         uint32_t incl = c;   // inclusive scan inside the wave
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -274,9 +280,11 @@ hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tri
                             uint32_t *counts, uint32_t *offsets, uint32_t *total_out, uint32_t bins_x, uint32_t bins_y, uint32_t capacity)
 {
     if (n_tris == 0 || bins_x == 0 || bins_y == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_bin_faces<false>), dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts, offsets, bins_x);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, counts, offsets, total_out, bins_x * bins_y, capacity);
-    hipLaunchKernelGGL((k_bin_faces<true>), dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts, offsets, bins_x);
+    uint32_t *counts4 = counts;                      // the counts buffer: four per bin (one per wave, 16-byte groups) ...
+    counts += 4u * (size_t)bins_x * bins_y;          // ... then the bins' own counts, which the render kernels read
+    hipLaunchKernelGGL((k_bin_faces<false>), dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts4, offsets, bins_x);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, counts4, counts, offsets, total_out, bins_x * bins_y, capacity);
+    hipLaunchKernelGGL((k_bin_faces<true>), dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts4, offsets, bins_x);
     return hipGetLastError();
 }
 
