@@ -168,3 +168,43 @@ def test_full_size_configs_on_selected_rows(rwr, orc, gpu_ctx, suzanne, name, w,
         assert np.abs(got["color"][r0:r1].astype(int) - want["color"][r0:r1].astype(int)).max() <= 1, (name, r0)
     if inst:
         assert len(np.unique(got["obj_id"][got["obj_id"] >= 0] // 111)) >= 12   # most of the 16 instances are visible (some occluded)
+
+
+@pytest.mark.parametrize("scene", ["suzanne_far", "grid"])
+def test_schedules_of_the_integrator_give_the_same_frame(rwr, orc, suzanne, scene):
+    """How the wavefront integrator spreads a frame over the chip is the host's choice and must not show: one or two launch
+    groups in flight, a tile's samples on one workgroup or several, every tile visited or only those the classification pass
+    lists (frames that show little), any group size, whole frame or row bands — all byte-identical, and equal to the oracle."""
+    import os
+    if scene == "suzanne_far":
+        w, h, eye, inst, spp = 200, 72, (0, 0, 3), None, 7
+    else:
+        w, h, eye, inst, spp = 256, 80, (0, 0, 12), rwr.make_instance_grid(4, 3.0), 6
+    cam_inv = rwr.camera_build_inv_uniform(rwr.make_camera(eye=eye, aspect=w / h))
+    params = rwr.make_params(spp=spp, max_bounces=1, seed=3, flags=rwr.FLAG_AUX_OUTPUTS)
+    want = orc.render_path(cam_inv.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), orc.make_params(spp, 1, seed=3),
+                           orc.make_spheres(), suzanne, instances=None if inst is None else inst.view(orc.INSTANCE_DTYPE))
+    keys = ("RWR_WF_ZSPLIT", "RWR_WF_OVERLAP", "RWR_WF_GROUP")
+    saved = {k: os.environ.get(k) for k in keys}
+    frames = []
+    try:
+        for zsplit, queues, group in (("1", "1", "32"), ("4", "1", "32"), ("3", "2", "2"), ("1", "2", "3"), ("0", "4", "1"), ("8", "3", "4")):
+            os.environ.update({"RWR_WF_ZSPLIT": zsplit, "RWR_WF_OVERLAP": queues, "RWR_WF_GROUP": group})
+            with rwr.Context(0) as ctx:        # the tunables are read when the context is created
+                got = _gpu(rwr, ctx, suzanne, rwr.make_spheres(), cam_inv, w, h, params, instances=inst)
+                again = _gpu(rwr, ctx, suzanne, rwr.make_spheres(), cam_inv, w, h, params, instances=inst)   # (zsplit 0: now from the first frame's live count)
+                band = _gpu(rwr, ctx, suzanne, rwr.make_spheres(), cam_inv, w, h, params, instances=inst, rows=(24, 56))
+            _check(got, want, spp)
+            for k in ("color", "color_f32", "depth", "obj_id", "hit_t"):
+                assert np.array_equal(got[k].view(np.uint8), again[k].view(np.uint8)), (zsplit, queues, group, k)
+                assert np.array_equal(got[k][24:56].view(np.uint8), band[k][24:56].view(np.uint8)), (zsplit, queues, group, k, "band")
+            frames.append(got)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for f in frames[1:]:
+        for k in ("color", "color_f32", "depth", "obj_id", "hit_t"):
+            assert np.array_equal(f[k].view(np.uint8), frames[0][k].view(np.uint8)), k
