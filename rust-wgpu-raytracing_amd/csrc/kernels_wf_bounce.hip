@@ -92,6 +92,7 @@ struct SortShared {
 // A pool is traced as PACKETS when it is well filled (min_fill rays) and its rays start close together compared
 // with the geometry (origins within bvh.packet_extent): then the rays of one direction bin really travel
 // together.  A tile that spans many small faces (a distant instance) is not such a pool.
+template <uint32_t NT>
 RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, const WfBuffers &wf, PoolInfo *__restrict__ info,
                        uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list, uint32_t n_tiles, uint32_t parity,
                        uint32_t sample_count, uint32_t min_fill, float packet_extent)
@@ -106,7 +107,7 @@ RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, co
         sh.masks[tid] = m;
         if (m) atomicAdd(&sh.total, (uint32_t)__popcll(m));
     }
-    for (uint32_t i = tid; i < kWfDirBins; i += 256u) sh.hist[i] = 0u;
+    for (uint32_t i = tid; i < kWfDirBins; i += NT) sh.hist[i] = 0u;
     __syncthreads();
     const uint32_t n_rays = sh.total;
     if (n_rays == 0u) {  // uniform
@@ -116,18 +117,19 @@ RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, co
     const size_t pool_base = (size_t)tile * wf.group * kWfTilePixels;
     bool packets = n_rays >= min_fill;
     if (packets) {   // uniform: how far apart do the rays start?  (the first two samples' slots)
-        float4 o[4];
-        bool live_slot[4];
+        constexpr int kPerThread = 1024 / (int)NT;
+        float4 o[kPerThread];
+        bool live_slot[kPerThread];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t e = tid + 256u * (uint32_t)u;
+        for (int u = 0; u < kPerThread; u++) {
+            const uint32_t e = tid + NT * (uint32_t)u;
             live_slot[u] = e < n_slots && ((sh.masks[e >> 6] >> (e & 63u)) & 1ull);
             o[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (live_slot[u]) o[u] = wf.rays[2u * (pool_base + e)];
         }
         uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < kPerThread; u++)
             if (live_slot[u]) {
                 const uint32_t k[3] = {float_key(o[u].x), float_key(o[u].y), float_key(o[u].z)};
 #pragma unroll
@@ -150,19 +152,19 @@ RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, co
         packets = ext <= packet_extent;   // a NaN extent: no packets
     }
     // histogram of the direction bins; e = sample * 512 + wave * 128 + k * 64 + lane
-    for (uint32_t e0 = tid; e0 < n_slots; e0 += 256u * 8u) {
+    for (uint32_t e0 = tid; e0 < n_slots; e0 += NT * 8u) {
         uint32_t bin[8];   // the primary stage stored every ray's bin beside it: 2 B to read instead of the 32-byte record
         bool live_slot[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const uint32_t e = e0 + 256u * (uint32_t)u;
+            const uint32_t e = e0 + NT * (uint32_t)u;
             live_slot[u] = e < n_slots && ((sh.masks[e >> 6] >> (e & 63u)) & 1ull);
             bin[u] = 0xffffu;
             if (live_slot[u]) bin[u] = min((uint32_t)wf.bins[pool_base + e], kWfDirBins - 1u);
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const uint32_t e = e0 + 256u * (uint32_t)u;
+            const uint32_t e = e0 + NT * (uint32_t)u;
             if (e < n_slots) {
                 s_bins[e] = (uint16_t)bin[u];
                 if (live_slot[u]) atomicAdd(&sh.hist[bin[u]], 1u);
@@ -170,25 +172,31 @@ RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, co
         }
     }
     __syncthreads();
-    {   // exclusive prefix over the bins: kPer consecutive bins per thread, shuffle scan inside a wave, four wave totals through LDS
+    {   // exclusive prefix over the bins by the first 256 threads: kPer consecutive bins each, shuffle scan inside a wave, four
+        // wave totals through LDS
         constexpr uint32_t kPer = kWfDirBins / 256u;
         static_assert(kWfDirBins % 2048u == 0u || kWfDirBins == 512u, "whole bins per thread, an octant starts at a thread's first bin");
-        uint32_t c[kPer], sum = 0;
+        const bool scan = tid < 256u;   // (whole waves)
+        uint32_t c[kPer], sum = 0, incl = 0;
+        if (scan) {
 #pragma unroll
-        for (uint32_t k = 0; k < kPer; k++) { c[k] = sh.hist[kPer * tid + k]; sum += c[k]; }
-        uint32_t incl = sum;
+            for (uint32_t k = 0; k < kPer; k++) { c[k] = sh.hist[kPer * tid + k]; sum += c[k]; }
+            incl = sum;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-            if ((int)(tid & 63u) >= d) incl += up;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if ((int)(tid & 63u) >= d) incl += up;
+            }
+            if ((tid & 63u) == 63u) sh.wave_sum[tid >> 6] = incl;
         }
-        if ((tid & 63u) == 63u) sh.wave_sum[tid >> 6] = incl;
         __syncthreads();
-        uint32_t before = incl - sum;
-        for (uint32_t w = 0; w < (tid >> 6); w++) before += sh.wave_sum[w];
-        if ((tid & 31u) == 0u) info[tile].oct_begin[tid >> 5] = before;   // octant o begins at bin (kWfDirBins / 8) o = kPer * (32 o)
+        if (scan) {
+            uint32_t before = incl - sum;
+            for (uint32_t w = 0; w < (tid >> 6); w++) before += sh.wave_sum[w];
+            if ((tid & 31u) == 0u) info[tile].oct_begin[tid >> 5] = before;   // octant o begins at bin (kWfDirBins / 8) o = kPer * (32 o)
 #pragma unroll
-        for (uint32_t k = 0; k < kPer; k++) { sh.offs[kPer * tid + k] = before; before += c[k]; }
+            for (uint32_t k = 0; k < kPer; k++) { sh.offs[kPer * tid + k] = before; before += c[k]; }
+        }
     }
     if (tid == 0u) {
         info[tile].oct_begin[8] = n_rays;
@@ -206,20 +214,24 @@ RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, co
     // scatter inside LDS (64 two-byte stores to 64 different places would cost the memory pipe a cycle each), then the
     // sorted list goes out in whole 16-byte pieces
     uint16_t *s_sorted = s_bins + n_slots;
-    for (uint32_t e = tid; e < n_slots; e += 256u) {
+    for (uint32_t e = tid; e < n_slots; e += NT) {
         const uint32_t bin = s_bins[e];
         if (bin != 0xffffu) s_sorted[atomicAdd(&sh.offs[bin], 1u)] = (uint16_t)e;
     }
     __syncthreads();
     uint4 *__restrict__ out = reinterpret_cast<uint4 *>(wf.sorted + pool_base);   // pool_base is a multiple of 512
     const uint4 *src = reinterpret_cast<const uint4 *>(s_sorted);
-    for (uint32_t i = tid; i < (n_rays + 7u) / 8u; i += 256u) out[i] = src[i];
+    for (uint32_t i = tid; i < (n_rays + 7u) / 8u; i += NT) out[i] = src[i];
 }
 
 // One workgroup per pool — or, on a frame that shows little, workgroups striding over the live tiles of k_wf_classify's list
 // (the other tiles emitted nothing and nobody looks at their pools).
+#ifndef RWR_SORT_THREADS
+#define RWR_SORT_THREADS 256
+#endif
+constexpr uint32_t kWfSortThreads = RWR_SORT_THREADS;   // (1024 measured the same as 256 on every config: the sort hides behind the other queue)
 template <bool LIST>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kWfSortThreads)
 k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list,
           uint32_t n_tiles, uint32_t parity, uint32_t sample_count, uint32_t min_fill, float packet_extent)
 {
@@ -227,13 +239,13 @@ k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     uint16_t *s_bins = reinterpret_cast<uint16_t *>(s_dyn);   // direction bin of every slot (0xffff: no ray), then the sorted list: 2 x 2 B x sample_count x 512
     if (!LIST) {
-        sort_pool(sh, s_bins, blockIdx.x, wf, info, counters, pool_list, n_tiles, parity, sample_count, min_fill, packet_extent);
+        sort_pool<kWfSortThreads>(sh, s_bins, blockIdx.x, wf, info, counters, pool_list, n_tiles, parity, sample_count, min_fill, packet_extent);
         return;
     }
     const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)*wf.live_count);
     for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)wf.live_list[t]);
-        sort_pool(sh, s_bins, tile, wf, info, counters, pool_list, n_tiles, parity, sample_count, min_fill, packet_extent);
+        sort_pool<kWfSortThreads>(sh, s_bins, tile, wf, info, counters, pool_list, n_tiles, parity, sample_count, min_fill, packet_extent);
         __syncthreads();   // (the next pool reuses the LDS)
     }
 }
@@ -666,10 +678,10 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
     const bool packets = bvh.stack_depth <= 64u && packet_min_rays <= sample_count * kWfTilePixels && bvh.packet_extent > 0.0f;
     const size_t sort_lds = 2u * (size_t)sample_count * kWfTilePixels * sizeof(uint16_t);
     if (wf.live_list)
-        hipLaunchKernelGGL(k_wf_sort<true>, dim3(std::min(n_tiles, 2048u)), dim3(256), sort_lds, s, wf, info, counters, pool_list, n_tiles, parity,
+        hipLaunchKernelGGL(k_wf_sort<true>, dim3(std::min(n_tiles, 2048u)), dim3(kWfSortThreads), sort_lds, s, wf, info, counters, pool_list, n_tiles, parity,
                            sample_count, packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);
     else
-        hipLaunchKernelGGL(k_wf_sort<false>, dim3(n_tiles), dim3(256), sort_lds, s, wf, info, counters, pool_list, n_tiles, parity,
+        hipLaunchKernelGGL(k_wf_sort<false>, dim3(n_tiles), dim3(kWfSortThreads), sort_lds, s, wf, info, counters, pool_list, n_tiles, parity,
                            sample_count, packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);
     const dim3 grid(std::min(kWfTraceGroups, n_tiles * kWfMaxSplit));
     const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0;
