@@ -286,10 +286,14 @@ def main() -> int:
         else:
             # wavefront: SURVEY §8(d) contract figure, 96 B per path segment + 20 B per pixel per frame
             algo_bytes = int(96 * rays_per_frame / world + 20 * w * (r1 - r0))
-            kernel = "k_wf_primary + k_wf_bounce + k_wf_resolve (all launches of one frame)"
-            note = ("VALU-bound (BVH traversal of incoherent rays).  hbm.achieved uses SURVEY §8(d)'s contract figure, 96 B per path "
+            kernel = "k_wf_primary + k_wf_sort + k_wf_trace_packet + k_wf_trace_lane + k_wf_resolve (all launches of one frame)"
+            note = ("VALU-bound (shading and BVH traversal).  hbm.achieved uses SURVEY §8(d)'s contract figure, 96 B per path "
                     "segment (ray + hit record, written and read) + 20 B per pixel, which this design deliberately does not move "
-                    "(primary rays and hit records stay in registers): traffic is what the counters saw")
+                    "(primary rays and hit records stay in registers) — so that fraction can exceed 1 and is kept only for "
+                    "comparability; hbm.design_bytes_per_step is what THIS design's algorithm moves (per bounce ray: 32-B record "
+                    "written and read, 2-B direction bin and 2-B sorted slot written and read; per pixel: 4 u64 sums added to by the "
+                    "primary stage and 3 by the trace kernels in every launch group, all 4 read + cleared by the resolve, 4 B RGBA8 — "
+                    "an upper bound: tiles that see nothing are never touched), and traffic is what the counters saw")
         # Counters of the dominant kernel(s) per step from the committed PMC passes (they cannot be collected live
         # inside this process); valid only for the exact workload they were measured on.
         counters = None
@@ -315,6 +319,11 @@ def main() -> int:
         hbm_achieved = algo_bytes / launch_s / 1e9
         hbm = {"achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 5),
                "algorithmic_bytes_per_step": algo_bytes}
+        if not primary_only_cfg:
+            n_groups = -(-cfg["spp"] // 32)   # launch groups of 32 samples
+            design = int(float(bounce_rays) * (2 * 32 + 2 * 2 + 2 * 2) + w * (r1 - r0) * (n_groups * 7 * 16 + 4 * 16 + 4))
+            hbm.update({"design_bytes_per_step": design, "design_frac": round(design / launch_s / 1e9 / HBM_PEAK_GBS, 5),
+                        "traffic_frac": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 5) if traffic else None})
         if valu:
             roofline = {"bound": "valu", "kernel": kernel, "achieved": valu["issue_us_per_step"], "peak": round(launch_s * 1e6, 3),
                         "unit": "us of VALU issue per step / us per step", "frac": valu["frac"], "traffic": traffic}

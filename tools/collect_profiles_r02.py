@@ -27,24 +27,27 @@ def pmc(cfg):
     return out
 
 
-def per_frame(cfg, frames_of_stats_run):
+def per_frame(cfg):
+    """launches per steady-state frame: calls / frames, frames = launches of the resolve step (one per frame); kernels of
+    the first frame's schedule alone (before the host knows how little a frame shows) round to zero"""
     calls = {}
     for r in csv.DictReader(open(os.path.join(SRC, f"kernel_stats_{cfg}.csv"))):
-        calls[r["Name"].split("(")[0]] = int(r["Calls"]) / frames_of_stats_run
-    return calls
+        calls[r["Name"].split("(")[0]] = int(r["Calls"])
+    frames = max(v for k, v in calls.items() if "k_wf_resolve" in k)
+    return {k: float(round(v / frames)) for k, v in calls.items()}
 
 
 counters = {"_note": "per-step (= per-frame) sums over the kernels of one frame, from rocprofv3 --kernel-trace --pmc passes (tools/pmc2.sh, "
                      "one counter group per run; per-launch means x launches per frame); FETCH_SIZE doubled on gfx950 (64 B counted per "
                      "128-B read request), WRITE_SIZE taken as reported (MI355X_MICROARCH.md HBM section); KB -> bytes x 1024"}
-FRAMES = {"cfg2": None, "cfg3": 7, "cfg4": 11}   # frames the kernel-stats runs rendered (warm-up + timed + probe segments)
-for cfg in ("cfg2", "cfg3", "cfg4"):
+CFGS = ("cfg2", "cfg3", "cfg4", "cfg5")
+for cfg in CFGS:
     p = pmc(cfg)
     kernels = [k for k in p if any(t in k for t in ("k_primary_p2", "k_wf_", "k_bin_", "k_frame_setup"))]
     if cfg == "cfg2":
         per = {k: 1.0 for k in kernels}
     else:
-        per = per_frame(cfg, FRAMES[cfg])
+        per = per_frame(cfg)
     tot = {"SQ_ACTIVE_INST_VALU": 0.0, "SQ_INSTS_VALU": 0.0, "FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0}
     detail = {}
     for k in kernels:
@@ -61,6 +64,6 @@ for cfg in ("cfg2", "cfg3", "cfg4"):
     counters[cfg] = {"source": f"profiles/r02_pmc_{cfg}_summary.txt", **{k: round(v, 1) for k, v in tot.items()},
                      "traffic_bytes_per_step": traffic, "kernels": detail}
 json.dump(counters, open(os.path.join(DST, "r02_counters.json"), "w"), indent=1)
-for cfg in ("cfg2", "cfg3", "cfg4"):
+for cfg in CFGS:
     c = counters[cfg]
     print(cfg, {k: v for k, v in c.items() if k != "kernels"})
