@@ -2,7 +2,10 @@
 # Round-2 evidence: bench lines, kernel stats and PMC passes for every configuration DESIGN.md quotes.
 # Writes gpurun_out/profile_r02/; tools/collect_profiles_r02.py copies the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/profile_r02; rm -rf $O; mkdir -p $O
+# usage: tools/profile_round2.sh counters   (kernel stats + PMC passes; then run tools/collect_profiles_r02.py here)
+#        tools/profile_round2.sh bench      (the bench lines, which quote the counters just collected)
+O=gpurun_out/profile_r02; mkdir -p $O
+if [ "$1" = "bench" ]; then
 b() { name=$1; shift; python3 bench.py "$@" > $O/bench_$name.json 2> $O/bench_$name.err; tail -c 400 $O/bench_$name.json | head -c 200; echo; }
 b default
 b driver_cmd --gpus 1 --steps 20 --warmup 5
@@ -12,6 +15,9 @@ b cfg4 --cpu-seconds 0 --config cfg4
 b cfg5_1gpu --cpu-seconds 0 --config cfg5
 b cfg2_force_dist --cpu-seconds 0 --force-dist
 b cfg5_force_dist --cpu-seconds 0 --force-dist --config cfg5
+ls $O | head -50
+exit 0
+fi
 k() { name=$1; shift; timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -- python3 bench.py --cpu-seconds 0 "$@" > $O/trace_$name.log 2>&1; cp $O/trace_$name/*/*kernel_stats.csv $O/kernel_stats_$name.csv; }
 k cfg2 --steps 500 --warmup 100
 k cfg2_one_in_flight --steps 500 --warmup 100 --frames-in-flight 1
