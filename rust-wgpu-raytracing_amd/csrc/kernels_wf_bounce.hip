@@ -23,11 +23,14 @@
 //                  3. shading of the second hit; the contribution albedo(h0) * E(h1) is added to the pool's
 //                     per-pixel sums in LDS as 64-bit FIXED-POINT atomics: integer sums do not depend on the
 //                     order in which rays retire, so the frame is bit-reproducible whatever the sort did.
-//                  4. one read-modify-write of the RGBA32F accumulator per pixel and group.
+//                  4. the work item's sums go to the frame's fixed-point planes (WfBuffers::fix) by integer atomics:
+//                     another share of the pool, the primary stage of the other launch group in flight or nobody may
+//                     be adding to the same pixels at the same time — the sums are the same bits.
+// On frames that show little the sort strides over the live tiles k_wf_classify listed instead of visiting every pool.
 //
 // Nothing here decides what the first hit shows; bounce rays are the oracle's rays bit for bit (first stage) and
-// their nearest hits are exact, so the stage's output differs from the oracle's only by float summation order
-// (tolerance 1e-4).
+// their nearest hits are exact, so the stage's output differs from the oracle's only by the fixed-point rounding
+// of the terms and of the throughput (tolerance 1e-4).
 #include <algorithm>
 #include <type_traits>
 
@@ -55,7 +58,7 @@ constexpr uint32_t kWfTraceGroups = 2048;  // workgroups of a trace launch (pers
 // (a packet is one long chain of dependent scalar loads; a handful of them on an otherwise idle chip take longer
 // than everything else in the frame).
 // device counters of one launch group (one set per ray queue, WfBuffers::counters): pools of each class, work items handed out
-enum { kLivePackets = 0, kLiveLane = 1, kWorkPackets = 2, kWorkLane = 3, kCountersPerParity = 4 };
+enum { kLivePackets = 0, kLiveLane = 1, kWorkPackets = 2, kWorkLane = 3, kCountersPerQueue = 4 };
 
 // float -> uint32 key whose unsigned order is the float order
 RWR_DEV uint32_t float_key(float f)
@@ -94,7 +97,7 @@ struct SortShared {
 // together.  A tile that spans many small faces (a distant instance) is not such a pool.
 template <uint32_t NT>
 RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, const WfBuffers &wf, PoolInfo *__restrict__ info,
-                       uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list, uint32_t n_tiles, uint32_t parity,
+                       uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list, uint32_t n_tiles,
                        uint32_t sample_count, uint32_t min_fill, float packet_extent)
 {
     const uint32_t tid = threadIdx.x;
@@ -203,7 +206,7 @@ RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, co
         info[tile].n_rays = n_rays;
         info[tile].packets = packets ? 1u : 0u;
         // append to the class's pool list (order of arrival: any order gives the same frame)
-        const uint32_t pos = atomicAdd(&counters[parity * kCountersPerParity + (packets ? kLivePackets : kLiveLane)], 1u);
+        const uint32_t pos = atomicAdd(&counters[(packets ? kLivePackets : kLiveLane)], 1u);
         pool_list[(packets ? 0u : n_tiles) + pos] = tile;
         if (wf.dbg) {
             atomicAdd(&wf.dbg[packets ? 0 : 2], 1ull);
@@ -233,19 +236,19 @@ constexpr uint32_t kWfSortThreads = RWR_SORT_THREADS;   // (1024 measured the sa
 template <bool LIST>
 __global__ void __launch_bounds__(kWfSortThreads)
 k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list,
-          uint32_t n_tiles, uint32_t parity, uint32_t sample_count, uint32_t min_fill, float packet_extent)
+          uint32_t n_tiles, uint32_t sample_count, uint32_t min_fill, float packet_extent)
 {
     __shared__ SortShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     uint16_t *s_bins = reinterpret_cast<uint16_t *>(s_dyn);   // direction bin of every slot (0xffff: no ray), then the sorted list: 2 x 2 B x sample_count x 512
     if (!LIST) {
-        sort_pool<kWfSortThreads>(sh, s_bins, blockIdx.x, wf, info, counters, pool_list, n_tiles, parity, sample_count, min_fill, packet_extent);
+        sort_pool<kWfSortThreads>(sh, s_bins, blockIdx.x, wf, info, counters, pool_list, n_tiles, sample_count, min_fill, packet_extent);
         return;
     }
     const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)*wf.live_count);
     for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)wf.live_list[t]);
-        sort_pool<kWfSortThreads>(sh, s_bins, tile, wf, info, counters, pool_list, n_tiles, parity, sample_count, min_fill, packet_extent);
+        sort_pool<kWfSortThreads>(sh, s_bins, tile, wf, info, counters, pool_list, n_tiles, sample_count, min_fill, packet_extent);
         __syncthreads();   // (the next pool reuses the LDS)
     }
 }
@@ -292,16 +295,16 @@ RWR_DEV void flush_pool(TraceShared &sh, const FrameParams &p, const WfBuffers &
 // — from a device counter until the class's live x split items are handed out.  Returns false when none are left.
 // Contains barriers; uniform over the workgroup.
 RWR_DEV bool next_item(TraceShared &sh, const PoolInfo *__restrict__ info, uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list,
-                       uint32_t parity, uint32_t n_tiles, uint32_t want_packets, uint32_t min_packet_pools, uint32_t &tile, uint32_t &share,
+                       uint32_t n_tiles, uint32_t want_packets, uint32_t min_packet_pools, uint32_t &tile, uint32_t &share,
                        uint32_t &n_shares, PoolInfo &pi)
 {
-    const uint32_t live_p = counters[parity * kCountersPerParity + kLivePackets], live_l = counters[parity * kCountersPerParity + kLiveLane];
+    const uint32_t live_p = counters[kLivePackets], live_l = counters[kLiveLane];
     const bool demote = live_p < min_packet_pools;
     if (want_packets && demote) return false;
     const uint32_t live = want_packets ? live_p : live_l + (demote ? live_p : 0u);
     n_shares = pool_split(live);
     __syncthreads();   // everybody is done with the previous item (sh.item, sh.acc)
-    if (threadIdx.x == 0u) sh.item = atomicAdd(&counters[parity * kCountersPerParity + (want_packets ? kWorkPackets : kWorkLane)], 1u);
+    if (threadIdx.x == 0u) sh.item = atomicAdd(&counters[(want_packets ? kWorkPackets : kWorkLane)], 1u);
     __syncthreads();
     // (values read back from LDS are uniform, but only we know that: readfirstlane keeps everything derived from
     // them — and with it the traversal's node and face loads — on the scalar unit)
@@ -326,7 +329,7 @@ template <bool NODES_IN_LDS, bool NMAP, bool STACK16>
 __global__ void __launch_bounds__(256)
 k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
                 const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf, const PoolInfo *__restrict__ info,
-                uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list, uint32_t parity, uint32_t n_tiles)
+                uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list, uint32_t n_tiles)
 {
     __shared__ TraceShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -339,7 +342,7 @@ k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const S
     bool staged = false;
     uint32_t tile, share, n_shares;
     PoolInfo pi;
-    while (next_item(sh, info, counters, pool_list, parity, n_tiles, 0u, bvh.min_packet_pools, tile, share, n_shares, pi)) {
+    while (next_item(sh, info, counters, pool_list, n_tiles, 0u, bvh.min_packet_pools, tile, share, n_shares, pi)) {
         const uint32_t n_rays = pi.n_rays;
         if (share * 256u >= n_rays) continue;   // uniform
         if (NODES_IN_LDS && !staged) {
@@ -488,7 +491,7 @@ template <bool NMAP>
 __global__ void __launch_bounds__(256, RWR_PACKET_OCC)
 k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
                   const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf, const PoolInfo *__restrict__ info,
-                  uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list, uint32_t parity, uint32_t n_tiles)
+                  uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list, uint32_t n_tiles)
 {
     __shared__ TraceShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -497,7 +500,7 @@ k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const
     const const_ptr<TriRecord> tris_c = to_const_space(tris);
     uint32_t tile, share, n_shares;
     PoolInfo pi;
-    while (next_item(sh, info, counters, pool_list, parity, n_tiles, 1u, bvh.min_packet_pools, tile, share, n_shares, pi)) {
+    while (next_item(sh, info, counters, pool_list, n_tiles, 1u, bvh.min_packet_pools, tile, share, n_shares, pi)) {
     // packets never straddle an octant: packet q of octant o covers sorted[oct_begin[o] + 128 q ...)
     uint32_t n_packets = 0;
 #pragma unroll
@@ -672,28 +675,27 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
 {
     if (n_tiles == 0 || sample_count == 0) return hipSuccess;
     uint32_t *counters = wf.counters;   // this queue's set, zeroed by the primary stage that filled the queue
-    const uint32_t parity = 0u;
     PoolInfo *info = static_cast<PoolInfo *>(pool_info);
     // well-filled, compact pools: packet traversal (its one stack is a VGPR of 64 entries)
     const bool packets = bvh.stack_depth <= 64u && packet_min_rays <= sample_count * kWfTilePixels && bvh.packet_extent > 0.0f;
     const size_t sort_lds = 2u * (size_t)sample_count * kWfTilePixels * sizeof(uint16_t);
     if (wf.live_list)
-        hipLaunchKernelGGL(k_wf_sort<true>, dim3(std::min(n_tiles, 2048u)), dim3(kWfSortThreads), sort_lds, s, wf, info, counters, pool_list, n_tiles, parity,
+        hipLaunchKernelGGL(k_wf_sort<true>, dim3(std::min(n_tiles, 2048u)), dim3(kWfSortThreads), sort_lds, s, wf, info, counters, pool_list, n_tiles,
                            sample_count, packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);
     else
-        hipLaunchKernelGGL(k_wf_sort<false>, dim3(n_tiles), dim3(kWfSortThreads), sort_lds, s, wf, info, counters, pool_list, n_tiles, parity,
+        hipLaunchKernelGGL(k_wf_sort<false>, dim3(n_tiles), dim3(kWfSortThreads), sort_lds, s, wf, info, counters, pool_list, n_tiles,
                            sample_count, packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);
     const dim3 grid(std::min(kWfTraceGroups, n_tiles * kWfMaxSplit));
     const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0;
     if (packets) {
-        if (nmap) hipLaunchKernelGGL((k_wf_trace_packet<true>), grid, dim3(256), 0, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles);
-        else hipLaunchKernelGGL((k_wf_trace_packet<false>), grid, dim3(256), 0, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles);
+        if (nmap) hipLaunchKernelGGL((k_wf_trace_packet<true>), grid, dim3(256), 0, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, n_tiles);
+        else hipLaunchKernelGGL((k_wf_trace_packet<false>), grid, dim3(256), 0, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, n_tiles);
     }
     const bool stack16 = bvh.n_nodes <= 0x7fffu && fp.n_tris <= 4095u;   // node indices and leaf links (first << 3 | count - 1) in 15 bits
     const size_t fixed = (size_t)bvh.stack_depth * 256u * (stack16 ? 2u : 4u);
     const size_t node_bytes = (size_t)bvh.n_nodes * sizeof(BvhNode4);
     // nodelets go to LDS when the workgroup then still fits a CU at least four times (160 KiB LDS, 12 KiB static)
-#define RWR_LANE_LAUNCH(L, N, S16, BYTES) hipLaunchKernelGGL((k_wf_trace_lane<L, N, S16>), grid, dim3(256), BYTES, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, parity, n_tiles)
+#define RWR_LANE_LAUNCH(L, N, S16, BYTES) hipLaunchKernelGGL((k_wf_trace_lane<L, N, S16>), grid, dim3(256), BYTES, s, fp, tris, shade, bvh, tex, wf, info, counters, pool_list, n_tiles)
 #define RWR_LANE_LAUNCH2(L, BYTES) \
     if (nmap) { if (stack16) RWR_LANE_LAUNCH(L, true, true, BYTES); else RWR_LANE_LAUNCH(L, true, false, BYTES); } \
     else { if (stack16) RWR_LANE_LAUNCH(L, false, true, BYTES); else RWR_LANE_LAUNCH(L, false, false, BYTES); }

@@ -8,13 +8,15 @@
 //                  FrameTri records, face records in scalar registers, no LDS, no barrier.  Per sample: jittered
 //                  ray (counter-based RNG keyed by GLOBAL pixel, sample, seed), spheres + mesh with the
 //                  reference's depth compositing, local shading E(h0); the group's E(h0) are summed in
-//                  registers in sample order and the RGBA32F accumulator is read and written ONCE per group
-//                  (16 + 16 B per pixel per group instead of per sample).  A pixel that hit a surface builds
+//                  registers as fixed point and added to the frame's integer planes ONCE per group (not per
+//                  sample).  A pixel that hit a surface builds
 //                  its cosine-distributed bounce ray and stores it at its FIXED slot of the ray queue in HBM
 //                  (coalesced 16-byte stores, rwr_internal.h WfBuffers); the wave publishes the ballot of the
 //                  lanes that emitted.  Compaction — ballot + prefix popcount — happens in the consumer
 //                  (kernels_wf_bounce.hip), folded into the sort of the tile's ray pool by direction.
 //                  Rays that left the scene cost nothing downstream.
+//   k_wf_classify  frames that show little: lists the tiles anything can be seen through, so that k_wf_primary<LIST>
+//                  takes (listed tile, share of its samples) items instead of grid coordinates (see there).
 //
 // Everything that decides what a sample sees (ray, hit tests, selection, depth, bounce ray) is written operation
 // for operation like the oracle, so sample-0 planes are bit-exact and every bounce ray is the oracle's.
