@@ -300,7 +300,7 @@ int main(int argc, char **argv)
     if (S > 1) {
         const int tw = argc > 4 ? atoi(argv[4]) : 64, th = argc > 5 ? atoi(argv[5]) : 8;
         for (int nb : {1, 4, 8, 16, 32}) {
-            long c = 0; size_t nr = 0; long pk_cost = 0, pk_n = 0, pk_f = 0, pk_w = 0;
+            long c = 0; size_t nr = 0; long pk_cost = 0, pk_n = 0, pk_f = 0, pk_w = 0; long pk_stage[5] = {0, 0, 0, 0, 0};
             for (int by = 0; by < rows; by += th)
                 for (int bx = 0; bx < w; bx += tw) {
                     struct E { int bin; RayTrace r; };
@@ -325,11 +325,11 @@ int main(int argc, char **argv)
                         for (size_t e = base; e < std::min(pool.size(), base + 128); e++)
                             for (auto &st : pool[e].r.steps) {
                                 if (st.kind == 0) seen_n[st.id] = 1;
-                                else for (int k = 0; k < st.nf; k++) seen_f[st.id + k] = 1;
+                                else for (int k = 0; k < st.nf; k++) seen_f[st.id + k] = std::max<uint8_t>(seen_f[st.id + k], st.stages[k]);
                             }
                         long un = 0, uf = 0;
                         for (auto v : seen_n) un += v;
-                        for (auto v : seen_f) uf += v;
+                        for (auto v : seen_f) { uf += v ? 1 : 0; pk_stage[v]++; }
                         pk_cost += un * 130 + uf * 125 + 100; pk_n += un; pk_f += uf; pk_w++;
                     }
                     for (size_t base = 0; base < pool.size(); base += 64) {
@@ -338,6 +338,8 @@ int main(int argc, char **argv)
                         c += run_wave_static(L) + 40;
                     }
                 }
+            printf("   faces per packet by the deepest stage any ray reached (1 plane .. 4 all edges): %.2f %.2f %.2f %.2f\n",
+                   (double)pk_stage[1] / pk_w, (double)pk_stage[2] / pk_w, (double)pk_stage[3] / pk_w, (double)pk_stage[4] / pk_w);
             printf("pool of %d samples x tile sorted into %3d direction bins : %8.1f wave-instr per ray; packets of 128: %.1f nodes + %.1f faces -> %.1f wave-instr per ray\n",
                    S, nb * nb, (double)c / nr, (double)pk_n / pk_w, (double)pk_f / pk_w, (double)pk_cost / nr);
         }
