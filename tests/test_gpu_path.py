@@ -208,3 +208,29 @@ def test_schedules_of_the_integrator_give_the_same_frame(rwr, orc, suzanne, scen
     for f in frames[1:]:
         for k in ("color", "color_f32", "depth", "obj_id", "hit_t"):
             assert np.array_equal(f[k].view(np.uint8), frames[0][k].view(np.uint8)), k
+
+
+def test_live_tile_list_without_a_bounce(rwr, orc, suzanne):
+    """Several samples, no bounce, on a frame that shows little: the classification pass and the listed-tile primary stage run
+    without a ray queue behind them."""
+    import os
+    w, h, spp = 200, 72, 5
+    cam_inv = rwr.camera_build_inv_uniform(rwr.make_camera(eye=(0, 0, 3), aspect=w / h))
+    params = rwr.make_params(spp=spp, max_bounces=0, seed=11, flags=rwr.FLAG_AUX_OUTPUTS)
+    want = orc.render_path(cam_inv.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), orc.make_params(spp, 0, seed=11),
+                           orc.make_spheres(), suzanne)
+    saved = os.environ.get("RWR_WF_ZSPLIT")
+    frames = []
+    try:
+        for zsplit in ("1", "4"):
+            os.environ["RWR_WF_ZSPLIT"] = zsplit
+            with rwr.Context(0) as ctx:
+                frames.append(_gpu(rwr, ctx, suzanne, rwr.make_spheres(), cam_inv, w, h, params))
+            _check(frames[-1], want, spp)
+    finally:
+        if saved is None:
+            os.environ.pop("RWR_WF_ZSPLIT", None)
+        else:
+            os.environ["RWR_WF_ZSPLIT"] = saved
+    for k in ("color", "color_f32", "depth", "obj_id", "hit_t"):
+        assert np.array_equal(frames[0][k].view(np.uint8), frames[1][k].view(np.uint8)), k
