@@ -40,11 +40,11 @@ def per_frame(cfg):
 counters = {"_note": "per-step (= per-frame) sums over the kernels of one frame, from rocprofv3 --kernel-trace --pmc passes (tools/pmc2.sh, "
                      "one counter group per run; per-launch means x launches per frame); FETCH_SIZE doubled on gfx950 (64 B counted per "
                      "128-B read request), WRITE_SIZE taken as reported (MI355X_MICROARCH.md HBM section); KB -> bytes x 1024"}
-CFGS = ("cfg2", "cfg3", "cfg4", "cfg5")
+CFGS = ("cfg2", "cfg2b", "cfg3", "cfg4", "cfg5")
 for cfg in CFGS:
     p = pmc(cfg)
     kernels = [k for k in p if any(t in k for t in ("k_primary_p2", "k_wf_", "k_bin_", "k_frame_setup"))]
-    if cfg == "cfg2":
+    if cfg in ("cfg2", "cfg2b"):   # the reference frame: one launch of each per frame
         per = {k: 1.0 for k in kernels}
     else:
         per = per_frame(cfg)

@@ -25,6 +25,7 @@ k cfg3 --config cfg3 --steps 3 --warmup 1
 k cfg4 --config cfg4 --steps 10 --warmup 2
 k cfg5 --config cfg5 --steps 5 --warmup 2
 tools/pmc2.sh $O/pmc_cfg2 "--steps 200 --warmup 20" inst cyc fetch write > $O/pmc_cfg2.txt 2>&1
+tools/pmc2.sh $O/pmc_cfg2b "--config cfg2b --steps 200 --warmup 20" inst cyc fetch write > $O/pmc_cfg2b.txt 2>&1
 tools/pmc2.sh $O/pmc_cfg3 "--config cfg3 --steps 1 --warmup 1" inst cyc fetch write > $O/pmc_cfg3.txt 2>&1
 tools/pmc2.sh $O/pmc_cfg4 "--config cfg4 --steps 3 --warmup 2" inst cyc fetch write > $O/pmc_cfg4.txt 2>&1
 tools/pmc2.sh $O/pmc_cfg5 "--config cfg5 --steps 2 --warmup 2" inst cyc fetch write > $O/pmc_cfg5.txt 2>&1
