@@ -12,15 +12,52 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "camera.hpp"
 #include "circle_camera_control.hpp"
-#include "models/sphere.hpp"
-#include "models/triangle_list.hpp"
 #include "resources.hpp"
 
 namespace rwr {
+
+// The reference's two model objects as State holds them (src/models/): each owns wgpu buffers and a compute pipeline
+// there; here they are what those buffers contain — the pipelines are the fused HIP kernel behind rwr_render.
+namespace models {
+
+// models::sphere::Sphere (sphere.rs:4-133): the 16-byte uniform, uploaded with rwr_scene_set_spheres
+class Sphere {
+public:
+    Sphere(float radius, Vector3 center) : data_{{center.x, center.y, center.z}, radius} {}  // sphere.rs:18-23
+    const SphereBufferData &get_buffer() const { return data_; }                              // sphere.rs:123-125
+
+private:
+    SphereBufferData data_;
+};
+
+// models::triangle_list::TriangleList (triangle_list.rs:6-250): takes the Model by value (:79), derives MaterialData from
+// materials[0] (:212) and exposes meshes[0]'s vertex / index buffers and materials[0]'s texture (:228-246) — the pieces
+// rwr_scene_upload_mesh receives
+class TriangleList {
+public:
+    explicit TriangleList(model::Model m) : model_(std::move(m))
+    {
+        const model::Material &mat = model_.materials.at(0);
+        material_ = MaterialData{{mat.ambient[0], mat.ambient[1], mat.ambient[2]}, 0.0f,
+                                 {mat.diffuse[0], mat.diffuse[1], mat.diffuse[2]}, 0.0f,
+                                 {mat.specular[0], mat.specular[1], mat.specular[2]}, 0.0f};
+    }
+    const std::vector<ModelVertexSmall> &get_vertex_buffer() const { return model_.meshes.at(0).vertex_buffer; }
+    const std::vector<ModelFaceSmall> &get_index_buffer() const { return model_.meshes.at(0).index_buffer; }
+    const MaterialData &get_material_buffer() const { return material_; }
+    const texture::Texture &get_texture() const { return model_.materials.at(0).diffuse_texture; }
+
+private:
+    model::Model model_;
+    MaterialData material_;
+};
+
+}  // namespace models
 
 struct RwrFailure : std::runtime_error {
     int code;
