@@ -995,14 +995,17 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
                 ctx->h_wf_live[0] = ctx->h_wf_live[1] = 0u;
             }
         }
-        // How many workgroups share a tile's samples in the primary stage: one when the frame fills the chip, more when the
-        // previous frame found only a few live tiles (its count arrives through pinned memory, a frame late, never waited
-        // for).  Any split gives the same frame: all sums are integers.
+        // Did the frame before show LITTLE — fewer than 1 024 live tiles, and at most half of this frame's tiles (a small mesh
+        // on an empty screen; not a small frame full of geometry, such as a row band of a multi-GPU frame: measured, that one
+        // is best left alone)?  Its count arrives through pinned memory, a frame late, never waited for.  Then up to 8
+        // workgroups share a tile's samples in the primary stage, and the tiles anything can be seen through are listed
+        // first (below).  Any choice gives the same frame: all sums are integers.
+        const uint32_t live = ctx->h_wf_live ? ctx->h_wf_live[0] + ctx->h_wf_live[1] : 0u;
+        const bool shows_little = live != 0u && live < 1024u && 2u * live <= n_tiles;
         uint32_t z_split = ctx->wf_z_split;
         if (z_split == 0u) {
             z_split = 1u;
-            const uint32_t live = ctx->h_wf_live ? ctx->h_wf_live[0] + ctx->h_wf_live[1] : 0u;
-            if (live != 0u && live < 1024u)
+            if (shows_little)
                 while (z_split < 8u && z_split * live < 2048u) z_split *= 2u;
         }
         // queue q: its half of every per-group buffer and its set of four counters (the primary stage zeroes the set it
@@ -1011,7 +1014,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         // A frame expected to show little (z_split > 1: the previous frame did) first lists the tiles anything can be seen
         // through; the primary stage, the sort and the resolve then touch those alone.  Same frame either way.
         uint32_t *live_list = nullptr, *live_count = nullptr, *tile_live = nullptr;
-        if (z_split > 1u && !(rp.flags & RWR_FLAG_NO_CULL)) {
+        if (z_split > 1u && (shows_little || ctx->wf_z_split != 0u) && !(rp.flags & RWR_FLAG_NO_CULL)) {   // (a forced split: the tests' way in)
             RWR_HIP_CHECK(ctx->d_wf_tiles.ensure(2u * (size_t)n_tiles + 1u));
             live_list = ctx->d_wf_tiles.ptr; tile_live = live_list + n_tiles; live_count = tile_live + n_tiles;
             RWR_HIP_CHECK(hipMemsetAsync(live_count, 0, sizeof(uint32_t), stream));

@@ -71,12 +71,14 @@ RWR_DEV float key_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ?
 // Into how many work items a pool of a class with `live` pools in this launch group is cut: one when the frame
 // keeps the chip busy by itself, up to kWfMaxSplit when only a few tiles see anything (a small mesh on an empty
 // screen: otherwise four waves would walk through a pool of thousands of rays one after the other while 250 CUs idle).
-RWR_DEV uint32_t pool_split(uint32_t live)
+RWR_DEV uint32_t pool_split(uint32_t live, bool packets)
 {
     if (live == 0u) return 1u;
-    // many pools: just enough pieces that the last round of work items is short (measured at configs[2], 4 050 pools: two
-    // shares beat one by 8 % and five by 6 % — every share flushes its sums); few pools: one 256-ray chunk per item
-    const uint32_t target = live >= kWfWholePools ? kWfTargetItemsDense : kWfTargetItems;
+    // just enough pieces that every workgroup gets a few items and the last round is short: every share zeroes and flushes
+    // 12 KiB of sums (measured at configs[2], 4 050 packet pools: two shares beat one by 8 % and five by 6 %; a 135-row band
+    // of the same frame, 510 packet pools: 8 shares, not 32 — 2.9 -> 1.9 ms).  Few pools of the per-lane class (a small mesh on
+    // an empty screen: their rays are few, the traversals long): one 256-ray chunk per item.
+    const uint32_t target = (packets || live >= kWfWholePools) ? kWfTargetItemsDense : kWfTargetItems;
     return min(kWfMaxSplit, max(1u, (target + live - 1u) / live));
 }
 
@@ -230,9 +232,10 @@ RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, co
 // One workgroup per pool — or, on a frame that shows little, workgroups striding over the live tiles of k_wf_classify's list
 // (the other tiles emitted nothing and nobody looks at their pools).
 #ifndef RWR_SORT_THREADS
-#define RWR_SORT_THREADS 256
+#define RWR_SORT_THREADS 1024
 #endif
-constexpr uint32_t kWfSortThreads = RWR_SORT_THREADS;   // (1024 measured the same as 256 on every config: the sort hides behind the other queue)
+constexpr uint32_t kWfSortThreads = RWR_SORT_THREADS;   // (a pool's sort is all latency; on whole frames 256 and 1024 measure the same — the
+                                                        // sort hides behind the other queue — on a band of 510 pools 1024 is 3x faster)
 template <bool LIST>
 __global__ void __launch_bounds__(kWfSortThreads)
 k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list,
@@ -302,7 +305,7 @@ RWR_DEV bool next_item(TraceShared &sh, const PoolInfo *__restrict__ info, uint3
     const bool demote = live_p < min_packet_pools;
     if (want_packets && demote) return false;
     const uint32_t live = want_packets ? live_p : live_l + (demote ? live_p : 0u);
-    n_shares = pool_split(live);
+    n_shares = pool_split(live, want_packets != 0u);
     __syncthreads();   // everybody is done with the previous item (sh.item, sh.acc)
     if (threadIdx.x == 0u) sh.item = atomicAdd(&counters[(want_packets ? kWorkPackets : kWorkLane)], 1u);
     __syncthreads();

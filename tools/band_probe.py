@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Renders one row band of a bench configuration a few times (for a kernel trace): python tools/band_probe.py cfg3 0 135"""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+rwr = importlib.import_module("rust-wgpu-raytracing_amd")
+name, r0, r1 = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+cfg = bench.CONFIGS[name]
+w, h = cfg["width"], cfg["height"]
+ctx = rwr.Context(0)
+ctx.upload_model(rwr.load_model_compute(cfg["scene"]))
+ctx.set_spheres(rwr.make_spheres())
+if cfg.get("instances"):
+    ctx.set_instances(rwr.make_instance_grid(cfg["instances"], 3.0))
+ctx.resize(w, h)
+cam_inv = rwr.camera_build_inv_uniform(rwr.make_camera(aspect=w / h, **cfg["camera"]))
+render = ctx.render_call(cam_inv, rwr.make_params(spp=cfg["spp"], max_bounces=cfg["bounces"]), (r0, r1))
+for _ in range(3):
+    render()
+    ctx.synchronize()   # (the host learns how little the frame shows from the frame before: DESIGN §4.2)
+ctx.timer_begin()
+for _ in range(6): render()
+print(f"{name} rows [{r0},{r1}): {ctx.timer_end() / 6:.4f} ms per frame")
+ctx.close()
