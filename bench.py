@@ -8,9 +8,9 @@
 A "step" is one frame of the reference's render loop (clear + 2 sphere passes +
 mesh pass, /root/reference/src/lib.rs:1024-1184) through the C ABI of
 include/rwr_hip.h.  Scene, camera and targets are resident in HBM before the
-timed region.  With N > 1 the frame is split into N contiguous row bands (one
-process per GPU) and every step ends with ONE RCCL gather of the finished bands
-to rank 0 (north_star), issued by the library itself (rwr_dist_gather_rgba8; torch.distributed
+timed region.  With N > 1 the frame is split into N interleaved sets of 8-row strips (one
+process per GPU) and every step ends with ONE RCCL gather of the finished strips
+to rank 0 (north_star), issued by the library itself (rwr_dist_gather_strips_rgba8; torch.distributed
 only carries the communicator id and the barriers, over gloo) — total work is fixed, so
 "scaling" is "strong".
 
@@ -147,7 +147,11 @@ def main() -> int:
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     w, h = cfg["width"], cfg["height"]
-    r0, r1 = rwr.dist_band(rank, world, h)
+    # Partition of the frame across ranks: every world-th strip of 8 rows (rwr_render_strips) — each rank gets the same share of
+    # whatever part of the screen the scene covers (contiguous row bands leave six of eight ranks idle on configs[4]'s frame:
+    # tools/band_balance.py).  One rank: the whole frame.
+    n_strips = (h + rwr.STRIP_ROWS - 1) // rwr.STRIP_ROWS
+    my_rows = sum(min(rwr.STRIP_ROWS, h - s * rwr.STRIP_ROWS) for s in range(rank, n_strips, world))
     model = rwr.load_model_compute(cfg["scene"])
     cam_inv = rwr.camera_build_inv_uniform(rwr.make_camera(aspect=w / h, **cfg["camera"]))
     params = rwr.make_params(spp=cfg["spp"], max_bounces=cfg["bounces"])
@@ -174,14 +178,14 @@ def main() -> int:
     fif = args.frames_in_flight if args.frames_in_flight else (2 if (primary_only and not use_dist) else 1)
     ctx.set_frames_in_flight(fif)
 
-    render = ctx.render_call(cam_inv, params, (r0, r1))
+    render = ctx.render_call(cam_inv, params, strips=(rank, world)) if use_dist else ctx.render_call(cam_inv, params, rows=(0, h))
 
-    gather = ctx.dist_gather_call(0) if use_dist else None
+    gather = ctx.dist_gather_call(0, strips=True) if use_dist else None
 
     def step():
         render()
         if use_dist:
-            gather()   # the frame's single collective: every band to rank 0 (RCCL over xGMI), stream-ordered after the render
+            gather()   # the frame's single collective: every rank's strips to rank 0 (RCCL over xGMI), stream-ordered after the render
 
     def barrier():
         if use_dist:
@@ -240,7 +244,7 @@ def main() -> int:
         ctx.set_kernel_timing(0)
     render_only_ms = None
     if use_dist:
-        # outside the timed region: the same band WITHOUT the gather, so that the line shows how the frame's time
+        # outside the timed region: the same share WITHOUT the gather, so that the line shows how the frame's time
         # splits between rendering (which scales with the rank count) and the single collective (which does not)
         n_ro = max(20, min(300, args.steps // 4))
         ctx.timer_begin()
@@ -275,9 +279,9 @@ def main() -> int:
         launch_s = dev_ms * 1e-3 / args.steps
         primary_only_cfg = cfg["spp"] == 1 and cfg["bounces"] == 0
         if primary_only_cfg:
-            # dominant kernel: the fused frame kernel — one launch per step on this rank's band (plus the
+            # dominant kernel: the fused frame kernel — one launch per step on this rank's share (plus the
             # 13-workgroup k_frame_setup that precedes it on the same stream)
-            algo_bytes = ALGO_BYTES_PER_PIXEL * w * (r1 - r0)
+            algo_bytes = ALGO_BYTES_PER_PIXEL * w * my_rows
             kernel = "k_primary_p2"
             note = ("VALU-bound: the scene (face records + 4 MiB linear-float texture) is cache resident and HBM sees only the "
                     "8 B/pixel store (RGBA8 + R32F, each pixel once), so hbm.frac is small by construction (SURVEY §8(d)); "
@@ -285,7 +289,7 @@ def main() -> int:
                     "duration_us; duration_us = HIP-event time of the timed region / K launches")
         else:
             # wavefront: SURVEY §8(d) contract figure, 96 B per path segment + 20 B per pixel per frame
-            algo_bytes = int(96 * rays_per_frame / world + 20 * w * (r1 - r0))
+            algo_bytes = int(96 * rays_per_frame / world + 20 * w * my_rows)
             kernel = "k_wf_primary + k_wf_sort + k_wf_trace_packet + k_wf_trace_lane + k_wf_resolve (all launches of one frame)"
             note = ("VALU-bound (shading and BVH traversal).  hbm.achieved uses SURVEY §8(d)'s contract figure, 96 B per path "
                     "segment (ray + hit record, written and read) + 20 B per pixel, which this design deliberately does not move "
@@ -321,7 +325,7 @@ def main() -> int:
                "algorithmic_bytes_per_step": algo_bytes}
         if not primary_only_cfg:
             n_groups = -(-cfg["spp"] // 32)   # launch groups of 32 samples
-            design = int(float(bounce_rays) * (2 * 32 + 2 * 2 + 2 * 2) + w * (r1 - r0) * (n_groups * 7 * 16 + 4 * 16 + 4))
+            design = int(float(bounce_rays) * (2 * 32 + 2 * 2 + 2 * 2) + w * my_rows * (n_groups * 7 * 16 + 4 * 16 + 4))
             hbm.update({"design_bytes_per_step": design, "design_frac": round(design / launch_s / 1e9 / HBM_PEAK_GBS, 5),
                         "traffic_frac": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 5) if traffic else None})
         if valu:
@@ -342,14 +346,14 @@ def main() -> int:
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "ms_per_frame": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["label"], "width": w, "height": h, "spp": cfg["spp"], "bounces": cfg["bounces"],
-                       "faces": int(len(model["faces"])), "partition": f"{world} row band(s) + 1 RCCL gather" if world > 1 else "single GPU",
+                       "faces": int(len(model["faces"])), "partition": f"{world} interleaved sets of 8-row strips + 1 RCCL gather" if world > 1 else "single GPU",
                        "frames_in_flight": fif, "device": info["name"]},
             "roofline": roofline,
         }
         if serial_ms_per_frame is not None:
             out["ms_per_frame_one_in_flight"] = round(serial_ms_per_frame, 5)   # frame latency: each frame waits for the previous
         if render_only_ms is not None:
-            out["ms_per_frame_render_only"] = round(render_only_ms, 5)   # slowest rank's band, no gather (not timed above)
+            out["ms_per_frame_render_only"] = round(render_only_ms, 5)   # slowest rank's share, no gather (not timed above)
         if gathered_ok is not None:
             out["config"]["gathered_frame_ok"] = gathered_ok
     if use_dist:

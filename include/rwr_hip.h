@@ -252,6 +252,16 @@ RWR_API int rwr_render(rwr_context *ctx, const rwr_camera_inv_uniform *camera, c
 RWR_API int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera,
                             const rwr_render_params *params, uint32_t row_begin, uint32_t row_end);
 
+/* Same, restricted to every strip_stride-th STRIP of RWR_STRIP_ROWS rows, starting with strip first_strip
+ * (< strip_stride): rows 8 (first_strip + k strip_stride) + 0..7.  The INTERLEAVED partition of a frame across
+ * GPUs — rwr_render_strips(ctx, camera, params, rank, world) — gives every rank the same share of whatever part
+ * of the screen the scene covers; contiguous bands (rwr_render_rows) leave most ranks idle when it covers a few
+ * rows (measured: the x16 instanced grid of BASELINE configs[4] sits in two of eight bands).  Same global pixel
+ * addressing and RNG keys: strips assemble bit-identically. */
+#define RWR_STRIP_ROWS 8u
+RWR_API int rwr_render_strips(rwr_context *ctx, const rwr_camera_inv_uniform *camera,
+                              const rwr_render_params *params, uint32_t first_strip, uint32_t strip_stride);
+
 RWR_API int rwr_synchronize(rwr_context *ctx);
 
 /* Copies finished targets to host memory (synchronises first).  Any pointer may
@@ -286,6 +296,9 @@ RWR_API int rwr_dist_init(rwr_context *ctx, int rank, int world, const uint8_t i
 RWR_API int rwr_dist_band(uint32_t rank, uint32_t world, uint32_t height, uint32_t *row_begin, uint32_t *row_end);
 /* Collective, asynchronous (stream-ordered after the frame rendered last). */
 RWR_API int rwr_dist_gather_rgba8(rwr_context *ctx, int root);
+/* The same for the interleaved partition (every rank rendered rwr_render_strips(ctx, ..., rank, world)): each rank packs
+ * its strips into one message, the root deals the received strips out into the frame.  One grouped exchange per frame. */
+RWR_API int rwr_dist_gather_strips_rgba8(rwr_context *ctx, int root);
 /* Root only: device address of the assembled W*H*4 frame / copy to the host (waits for the gather). */
 RWR_API int rwr_dist_frame(rwr_context *ctx, void **d_rgba8);
 RWR_API int rwr_dist_readback(rwr_context *ctx, uint8_t *rgba8);

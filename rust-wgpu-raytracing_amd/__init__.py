@@ -101,7 +101,7 @@ def lib() -> C.CDLL:
         "rwr_scene_upload_model_all": [vp, vp], "rwr_model_part_normal_map": [vp, u32, vp, vp, vp],
         "rwr_scene_set_normal_map": [vp, u32, vp, u32, u32], "rwr_scene_part_count": [vp, vp],
         "rwr_scene_set_spheres": [vp, vp, u32], "rwr_scene_set_triangles": [vp, vp, u32], "rwr_scene_set_instances": [vp, vp, u32],
-        "rwr_resize": [vp, vp], "rwr_render": [vp, vp, vp], "rwr_render_rows": [vp, vp, vp, u32, u32],
+        "rwr_resize": [vp, vp], "rwr_render": [vp, vp, vp], "rwr_render_rows": [vp, vp, vp, u32, u32], "rwr_render_strips": [vp, vp, vp, u32, u32],
         "rwr_synchronize": [vp], "rwr_readback": [vp, vp, vp, vp, vp, vp], "rwr_get_device_targets": [vp, vp, vp],
         "rwr_timer_begin": [vp], "rwr_timer_end": [vp, vp], "rwr_timer_stop": [vp], "rwr_timer_elapsed": [vp, vp], "rwr_last_render_stats": [vp, vp, vp],
         "rwr_camera_build_inv_uniform": [vp, vp], "rwr_circle_controller_update": [f32, u32, vp],
@@ -113,7 +113,7 @@ def lib() -> C.CDLL:
         "rwr_ctx_set_kernel_timing": [vp, u32], "rwr_kernel_timing_stats": [vp, vp, vp],
         "rwr_selftest_exact_math": [vp, u32, u32, vp], "rwr_ctx_set_frames_in_flight": [vp, u32],
         "rwr_dist_get_unique_id": [vp], "rwr_dist_init": [vp, i32, i32, vp], "rwr_dist_band": [u32, u32, u32, vp, vp],
-        "rwr_dist_gather_rgba8": [vp, i32], "rwr_dist_frame": [vp, vp], "rwr_dist_readback": [vp, vp],
+        "rwr_dist_gather_rgba8": [vp, i32], "rwr_dist_gather_strips_rgba8": [vp, i32], "rwr_dist_frame": [vp, vp], "rwr_dist_readback": [vp, vp],
         "rwr_dist_barrier": [vp], "rwr_dist_destroy": [vp],
         "rwr_measure_valu_clock": [vp, u32, vp], "rwr_clock_probe_start": [vp, u32], "rwr_clock_probe_read": [vp, vp],
     }
@@ -267,6 +267,7 @@ def load_model_parts(file_name: str, res_dir: str = RES_DIR) -> list:
 
 # ----------------------------------------------------------------- multi-GPU frames --
 DIST_ID_BYTES = 128
+STRIP_ROWS = 8   # RWR_STRIP_ROWS
 
 
 def dist_get_unique_id() -> bytes:
@@ -380,18 +381,24 @@ class Context:
         _check(lib().rwr_resize(self._h, _p(make_screen(width, height))))
         self.width, self.height = width, height
 
-    def render(self, cam_inv, params=None, rows=None):
-        if rows is None:
+    def render(self, cam_inv, params=None, rows=None, strips=None):
+        """rows = (row_begin, row_end): a band (rwr_render_rows); strips = (first_strip, strip_stride): every strip_stride-th
+        8-row strip (rwr_render_strips); neither: the whole frame."""
+        if strips is not None:
+            _check(lib().rwr_render_strips(self._h, _p(cam_inv), _p(params), strips[0], strips[1]))
+        elif rows is None:
             _check(lib().rwr_render(self._h, _p(cam_inv), _p(params)))
         else:
             _check(lib().rwr_render_rows(self._h, _p(cam_inv), _p(params), rows[0], rows[1]))
 
-    def render_call(self, cam_inv, params, rows):
+    def render_call(self, cam_inv, params, rows=None, strips=None):
         """A zero-argument callable that enqueues one frame; arguments are marshalled
         once so that the per-frame host cost is one foreign call."""
-        fn, h = lib().rwr_render_rows, self._h
+        fn, h = (lib().rwr_render_strips if strips is not None else lib().rwr_render_rows), self._h
         a, b = _p(cam_inv), _p(params)
-        r0, r1 = C.c_uint32(rows[0]), C.c_uint32(rows[1])
+        if strips is None and rows is None:
+            rows = (0, self.height)
+        r0, r1 = (C.c_uint32(strips[0]), C.c_uint32(strips[1])) if strips is not None else (C.c_uint32(rows[0]), C.c_uint32(rows[1]))
 
         def call(_keep=(cam_inv, params)):
             rc = fn(h, a, b, r0, r1)
@@ -467,8 +474,9 @@ class Context:
         """The frame's single collective: every rank's finished RGBA8 band to `root` (RCCL, stream-ordered)."""
         _check(lib().rwr_dist_gather_rgba8(self._h, root))
 
-    def dist_gather_call(self, root: int = 0):
-        fn, h, r = lib().rwr_dist_gather_rgba8, self._h, C.c_int(root)
+    def dist_gather_call(self, root: int = 0, strips: bool = False):
+        """strips: the ranks rendered the interleaved partition (render(..., strips=(rank, world)))"""
+        fn, h, r = (lib().rwr_dist_gather_strips_rgba8 if strips else lib().rwr_dist_gather_rgba8), self._h, C.c_int(root)
 
         def call():
             rc = fn(h, r)

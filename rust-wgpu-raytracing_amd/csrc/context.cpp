@@ -186,6 +186,7 @@ struct rwr_context {
     ncclComm_t comm = nullptr;
     int dist_rank = 0, dist_world = 0;
     DeviceBuffer<uint8_t> d_gathered;    // root: the assembled RGBA8 frame
+    DeviceBuffer<uint8_t> d_strip_pack, d_strip_recv;   // interleaved partition: this rank's strips back to back; root: every rank's
     hipEvent_t gather_done = nullptr;    // orders consecutive gathers that run on different frame slots' streams
     bool gathered_valid = false;
     // shader-clock probe (rwr_clock_probe_start / _read): one spinning wave on its own stream
@@ -778,8 +779,10 @@ int rwr_resize(rwr_context *ctx, const rwr_screen *screen)
     return RWR_OK;
 }
 
-int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, const rwr_render_params *params,
-                    uint32_t row_begin, uint32_t row_end)
+// One frame — rows [row_begin, row_end) in strips of 8 rows, strip k starting at row_begin + k * row_pitch (row_pitch 8: the
+// whole band; 8 N: every N-th strip).
+static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, const rwr_render_params *params,
+                        uint32_t row_begin, uint32_t row_end, uint32_t row_pitch)
 {
     if (!ctx || !camera) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (ctx->screen.width == 0) return set_error(RWR_ERR_NOT_READY, "rwr_resize has not been called");
@@ -836,6 +839,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
     fp.height = ctx->screen.height;
     fp.row_begin = row_begin;
     fp.row_end = row_end;
+    fp.row_pitch = row_pitch;
     fp.n_spheres = ctx->n_spheres;
     for (uint32_t i = 0; i < ctx->n_spheres; i++) fp.spheres[i] = ctx->spheres[i];
     fp.n_tris = ctx->n_tris;
@@ -961,7 +965,7 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         // group's samples of every pixel, rays into the fixed-slot queue) then the bounce stage (one workgroup per
         // 64x8-pixel tile and its ray pool)
         const uint32_t group = std::min(rp.spp, ctx->wf_group);
-        const uint32_t tiles_x = (ctx->screen.width + kWfTileW - 1u) / kWfTileW, tiles_y = (row_end - row_begin + kWfTileH - 1u) / kWfTileH;
+        const uint32_t tiles_x = (ctx->screen.width + kWfTileW - 1u) / kWfTileW, tiles_y = band_strips(fp);
         const uint32_t n_tiles = tiles_x * tiles_y;
         RWR_HIP_CHECK(ctx->d_wave_total.ensure((size_t)n_tiles * 4u));
         RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wave_total.ptr, 0, (size_t)n_tiles * 4u * sizeof(uint32_t), stream));
@@ -1065,7 +1069,9 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
         ctx->timing_pairs++;
     }
     sl.aux_valid = aux;
-    ctx->last_primary = (uint64_t)ctx->screen.width * (row_end - row_begin) * rp.spp;
+    uint64_t rows_rendered = 0;   // the strips' rows inside [row_begin, row_end)
+    for (uint32_t y0 = row_begin; y0 < row_end; y0 += row_pitch) rows_rendered += std::min(kStripRows, row_end - y0);
+    ctx->last_primary = (uint64_t)ctx->screen.width * rows_rendered * rp.spp;
     ctx->last_bounce = 0;  // filled in lazily by rwr_last_render_stats from the pass counters
     return RWR_OK;
 }
@@ -1073,7 +1079,23 @@ int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, cons
 int rwr_render(rwr_context *ctx, const rwr_camera_inv_uniform *camera, const rwr_render_params *params)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
-    return rwr_render_rows(ctx, camera, params, 0, ctx->screen.height);
+    return render_frame(ctx, camera, params, 0, ctx->screen.height, kStripRows);
+}
+
+int rwr_render_rows(rwr_context *ctx, const rwr_camera_inv_uniform *camera, const rwr_render_params *params,
+                    uint32_t row_begin, uint32_t row_end)
+{
+    return render_frame(ctx, camera, params, row_begin, row_end, kStripRows);
+}
+
+int rwr_render_strips(rwr_context *ctx, const rwr_camera_inv_uniform *camera, const rwr_render_params *params,
+                      uint32_t first_strip, uint32_t strip_stride)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (strip_stride == 0u || first_strip >= strip_stride || strip_stride > 0x0fffffffu)
+        return set_error(RWR_ERR_INVALID_ARGUMENT, "strips %u, %u + %u, ...: the first strip must be below the stride", first_strip, first_strip, strip_stride);
+    const uint32_t h = ctx->screen.height, first_row = first_strip * kStripRows;
+    return render_frame(ctx, camera, params, std::min(first_row, h), h, strip_stride * kStripRows);
 }
 
 int rwr_synchronize(rwr_context *ctx)
@@ -1432,6 +1454,70 @@ int rwr_dist_gather_rgba8(rwr_context *ctx, int root)
     return RWR_OK;
 }
 
+// The interleaved partition (rwr_render_strips(ctx, ..., rank, world)): rank r owns strips r, r + world, ...  Every rank packs
+// its strips into one contiguous message (one strided device copy), the root receives the messages side by side and deals
+// the strips out into the frame (one strided device copy per rank): still ONE grouped RCCL exchange per frame.
+int rwr_dist_gather_strips_rgba8(rwr_context *ctx, int root)
+{
+    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (!ctx->comm) return set_error(RWR_ERR_NOT_READY, "rwr_dist_init has not been called");
+    if (root < 0 || root >= ctx->dist_world) return set_error(RWR_ERR_INVALID_ARGUMENT, "root %d outside world %d", root, ctx->dist_world);
+    if (ctx->screen.width == 0) return set_error(RWR_ERR_NOT_READY, "rwr_resize has not been called");
+    DeviceGuard g(ctx->device);
+    FrameSlot &sl = ctx->slots[ctx->cur];
+    const hipStream_t stream = sl.stream;   // the frame rendered last: the exchange follows it in stream order
+    const uint32_t h = ctx->screen.height, world = (uint32_t)ctx->dist_world;
+    const size_t row_bytes = (size_t)ctx->screen.width * 4u, strip_bytes = row_bytes * kStripRows;
+    const uint32_t n_strips = (h + kStripRows - 1u) / kStripRows, tail_rows = h % kStripRows;   // (the frame's last strip may be short)
+    // rank r: its strips, how many of them are whole, its rows
+    auto strips_of = [&](uint32_t r) { return r < n_strips ? (n_strips - r + world - 1u) / world : 0u; };
+    auto owns_tail = [&](uint32_t r) { return tail_rows != 0u && (n_strips - 1u) % world == r; };
+    auto rows_of = [&](uint32_t r) { return strips_of(r) * kStripRows - (owns_tail(r) ? kStripRows - tail_rows : 0u); };
+    const bool is_root = ctx->dist_rank == root;
+    const uint32_t me = (uint32_t)ctx->dist_rank;
+    RWR_HIP_CHECK(ctx->d_strip_pack.ensure((size_t)std::max(1u, rows_of(me)) * row_bytes));
+    if (is_root) {
+        RWR_HIP_CHECK(ctx->d_gathered.ensure(row_bytes * h));
+        RWR_HIP_CHECK(ctx->d_strip_recv.ensure(row_bytes * h));
+    }
+    if (ctx->n_slots > 1u) RWR_HIP_CHECK(hipStreamWaitEvent(stream, ctx->gather_done, 0));   // one set of buffers: gathers do not overlap
+    // pack: whole strips by one strided copy, the short last strip (if it is ours) behind them
+    const uint32_t my_whole = strips_of(me) - (owns_tail(me) ? 1u : 0u);
+    if (my_whole)
+        RWR_HIP_CHECK(hipMemcpy2DAsync(ctx->d_strip_pack.ptr, strip_bytes, sl.d_color.ptr + (size_t)me * strip_bytes, (size_t)world * strip_bytes,
+                                       strip_bytes, my_whole, hipMemcpyDeviceToDevice, stream));
+    if (owns_tail(me))
+        RWR_HIP_CHECK(hipMemcpyAsync(ctx->d_strip_pack.ptr + (size_t)my_whole * strip_bytes, sl.d_color.ptr + (size_t)(n_strips - 1u) * strip_bytes,
+                                     (size_t)tail_rows * row_bytes, hipMemcpyDeviceToDevice, stream));
+    RWR_NCCL_CHECK(g_rccl.GroupStart());
+    if (rows_of(me))
+        RWR_NCCL_CHECK(g_rccl.Send(ctx->d_strip_pack.ptr, (size_t)rows_of(me) * row_bytes, ncclUint8, root, ctx->comm, stream));
+    if (is_root) {
+        size_t at = 0;
+        for (uint32_t r = 0; r < world; r++) {
+            if (rows_of(r)) RWR_NCCL_CHECK(g_rccl.Recv(ctx->d_strip_recv.ptr + at, (size_t)rows_of(r) * row_bytes, ncclUint8, (int)r, ctx->comm, stream));
+            at += (size_t)rows_of(r) * row_bytes;
+        }
+    }
+    RWR_NCCL_CHECK(g_rccl.GroupEnd());
+    if (is_root) {   // deal the strips out into the frame
+        size_t at = 0;
+        for (uint32_t r = 0; r < world; r++) {
+            const uint32_t whole = strips_of(r) - (owns_tail(r) ? 1u : 0u);
+            if (whole)
+                RWR_HIP_CHECK(hipMemcpy2DAsync(ctx->d_gathered.ptr + (size_t)r * strip_bytes, (size_t)world * strip_bytes, ctx->d_strip_recv.ptr + at, strip_bytes,
+                                               strip_bytes, whole, hipMemcpyDeviceToDevice, stream));
+            if (owns_tail(r))
+                RWR_HIP_CHECK(hipMemcpyAsync(ctx->d_gathered.ptr + (size_t)(n_strips - 1u) * strip_bytes, ctx->d_strip_recv.ptr + at + (size_t)whole * strip_bytes,
+                                             (size_t)tail_rows * row_bytes, hipMemcpyDeviceToDevice, stream));
+            at += (size_t)rows_of(r) * row_bytes;
+        }
+    }
+    RWR_HIP_CHECK(hipEventRecord(ctx->gather_done, stream));
+    ctx->gathered_valid = is_root;
+    return RWR_OK;
+}
+
 int rwr_dist_frame(rwr_context *ctx, void **d_rgba8)
 {
     if (!ctx || !d_rgba8) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1478,6 +1564,8 @@ int rwr_dist_destroy(rwr_context *ctx)
     }
     if (ctx->gather_done) { (void)hipEventDestroy(ctx->gather_done); ctx->gather_done = nullptr; }
     ctx->d_gathered.release();
+    ctx->d_strip_pack.release();
+    ctx->d_strip_recv.release();
     ctx->gathered_valid = false;
     ctx->dist_world = 0;
     return RWR_OK;

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256)
 k_primary_dormant(const FrameParams p, const SingleTriangles st, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
                   const float4 *__restrict__ tex, const Targets tg)
 {
-    const uint32_t px = blockIdx.x * 32u + (threadIdx.x & 31u), py = p.row_begin + blockIdx.y * 8u + (threadIdx.x >> 5);
+    const uint32_t px = blockIdx.x * 32u + (threadIdx.x & 31u), py = p.row_begin + blockIdx.y * p.row_pitch + (threadIdx.x >> 5);
     const bool in_range = (px < p.width) && (py < p.row_end);
 
     f3 O = ld3(p.cam.origin), D;
@@ -101,7 +101,7 @@ hipError_t launch_primary_dormant(hipStream_t s, const FrameParams &fp, const Si
                                   const ShadeRec *shade, const float4 *tex, const Targets &tg)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
-    const dim3 grid((fp.width + 31u) / 32u, (fp.row_end - fp.row_begin + 7u) / 8u);
+    const dim3 grid((fp.width + 31u) / 32u, band_strips(fp));
     if (fp.flags & RWR_FLAG_AUX_OUTPUTS) hipLaunchKernelGGL(k_primary_dormant<true>, grid, dim3(256), 0, s, fp, st, tris, shade, tex, tg);
     else hipLaunchKernelGGL(k_primary_dormant<false>, grid, dim3(256), 0, s, fp, st, tris, shade, tex, tg);
     return hipGetLastError();

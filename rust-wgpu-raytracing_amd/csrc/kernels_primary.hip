@@ -300,7 +300,7 @@ k_primary(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRe
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t blk_x0 = blockIdx.x * 32u;
     const uint32_t tile_x0 = blk_x0 + wave * 8u;
-    const uint32_t tile_y0 = p.row_begin + blockIdx.y * 8u;
+    const uint32_t tile_y0 = p.row_begin + blockIdx.y * p.row_pitch;
     const uint32_t px = tile_x0 + (lane & 7u), py = tile_y0 + (lane >> 3);
     const bool in_range = (px < p.width) && (py < p.row_end);
 
@@ -336,7 +336,7 @@ hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord 
                           const FrameTri *ftris, const float4 *tex, const Targets &tg)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
-    const dim3 grid((fp.width + 31u) / 32u, (fp.row_end - fp.row_begin + 7u) / 8u);
+    const dim3 grid((fp.width + 31u) / 32u, band_strips(fp));
     const dim3 block(256);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
     const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;

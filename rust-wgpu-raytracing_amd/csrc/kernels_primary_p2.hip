@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256, (AUX || NMAP) ? 4 : RWR_P2_OCC)
 // (the first eleven arguments repeat FrameParams fields: they are what a wave needs first, and the Makefile
 // has their 14 dwords preloaded into SGPRs)
 k_primary_p2(const FrameTri *__restrict__ ftris, const float4 *__restrict__ ray_colp, const float4 *__restrict__ ray_row,
-             uint32_t n_tris, uint32_t row_begin, uint32_t bins_enabled, uint32_t pad0,
+             uint32_t n_tris, uint32_t row_begin, uint32_t bins_enabled, uint32_t row_pitch,
              int32_t mesh_x0, int32_t mesh_y0, int32_t mesh_x1, int32_t mesh_y1,
              const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
              const float4 *__restrict__ tex, const Targets tg)
@@ -39,12 +39,12 @@ k_primary_p2(const FrameTri *__restrict__ ftris, const float4 *__restrict__ ray_
     const uint32_t blk_x0 = blockIdx.x * 64u;
 #if RWR_P2_TILE_32x4
     const uint32_t tile_x0 = blk_x0 + (wave & 1u) * 32u;
-    const uint32_t tile_y0 = row_begin + blockIdx.y * 8u + (wave >> 1) * 4u;
+    const uint32_t tile_y0 = row_begin + blockIdx.y * row_pitch + (wave >> 1) * 4u;
     const uint32_t px0 = tile_x0 + 2u * (lane & 15u), py = tile_y0 + (lane >> 4);
     constexpr float kTileWf = 32.0f, kTileHf = 4.0f;
 #else
     const uint32_t tile_x0 = blk_x0 + wave * 16u;
-    const uint32_t tile_y0 = p.row_begin + blockIdx.y * 8u;
+    const uint32_t tile_y0 = p.row_begin + blockIdx.y * row_pitch;
     const uint32_t px0 = tile_x0 + 2u * (lane & 7u), py = tile_y0 + (lane >> 3);
     constexpr float kTileWf = 16.0f, kTileHf = 8.0f;
 #endif
@@ -65,10 +65,10 @@ k_primary_p2(const FrameTri *__restrict__ ftris, const float4 *__restrict__ ray_
     if (CULL) {  // the tile lies outside the screen rectangle of the whole mesh: scalar integer compares
         const int32_t wu = __builtin_amdgcn_readfirstlane((int32_t)wave);
 #if RWR_P2_TILE_32x4
-        const int32_t sx0 = (int32_t)blk_x0 + (wu & 1) * 32, sy0 = (int32_t)(row_begin + blockIdx.y * 8u) + (wu >> 1) * 4;
+        const int32_t sx0 = (int32_t)blk_x0 + (wu & 1) * 32, sy0 = (int32_t)(row_begin + blockIdx.y * row_pitch) + (wu >> 1) * 4;
         const int32_t sx1 = sx0 + 32, sy1 = sy0 + 4;
 #else
-        const int32_t sx0 = (int32_t)blk_x0 + wu * 16, sy0 = (int32_t)(row_begin + blockIdx.y * 8u);
+        const int32_t sx0 = (int32_t)blk_x0 + wu * 16, sy0 = (int32_t)(row_begin + blockIdx.y * row_pitch);
         const int32_t sx1 = sx0 + 16, sy1 = sy0 + 8;
 #endif
         if (sx1 < mesh_x0 || sx0 > mesh_x1 || sy1 < mesh_y0 || sy0 > mesh_y1) n_src = 0u;
@@ -230,7 +230,7 @@ hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriReco
                              hipEvent_t ev_stop)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
-    const dim3 grid((fp.width + 63u) / 64u, (fp.row_end - fp.row_begin + 7u) / 8u);
+    const dim3 grid((fp.width + 63u) / 64u, band_strips(fp));
     const dim3 block(256);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
     const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
@@ -238,7 +238,7 @@ hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriReco
     // kernel's own duration as a profiler reports it, without the gap to the preceding kernel
     const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0 && fp.tangents != nullptr;
 #define RWR_P2_LAUNCH(A, C, N) hipExtLaunchKernelGGL((k_primary_p2<A, C, N>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, \
-    fp.n_tris, fp.row_begin, fp.bins.enabled, 0u, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg)
+    fp.n_tris, fp.row_begin, fp.bins.enabled, fp.row_pitch, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg)
     if (nmap) {
         if (aux && do_cull) RWR_P2_LAUNCH(true, true, true);
         else if (aux) RWR_P2_LAUNCH(true, false, true);

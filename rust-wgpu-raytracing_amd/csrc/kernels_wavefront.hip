@@ -28,7 +28,7 @@ k_primary_bvh(const FrameParams p, const TriRecord *__restrict__ tris, const Sha
         __syncthreads();
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t px = blockIdx.x * 32u + wave * 8u + (lane & 7u), py = p.row_begin + blockIdx.y * 8u + (lane >> 3);
+    const uint32_t px = blockIdx.x * 32u + wave * 8u + (lane & 7u), py = p.row_begin + blockIdx.y * p.row_pitch + (lane >> 3);
     const bool in_range = (px < p.width) && (py < p.row_end);
     const f3 O = ld3(p.cam.origin);
     const f3 D = pixel_to_ray_dir(p.cam, px, py, 0.5f, 0.5f, p.width, p.height);
@@ -46,7 +46,7 @@ k_primary_bvh(const FrameParams p, const TriRecord *__restrict__ tris, const Sha
     MeshHit best;
     best.have = false; best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.ndotd = 0.0f; best.idx = 0u;
     // wave-uniform: the wave's 8x8 tile lies outside the screen rectangle of the whole mesh (FrameParams::mesh_rect)
-    const float tx = (float)(blockIdx.x * 32u + wave * 8u), ty = (float)(p.row_begin + blockIdx.y * 8u);
+    const float tx = (float)(blockIdx.x * 32u + wave * 8u), ty = (float)(p.row_begin + blockIdx.y * p.row_pitch);
     const bool outside = !(p.flags & RWR_FLAG_NO_CULL) && ((tx + 8.0f < p.mesh_rect[0]) || (tx > p.mesh_rect[2]) ||
                                                           (ty + 8.0f < p.mesh_rect[1]) || (ty > p.mesh_rect[3]));
     if (p.n_tris && !outside) {
@@ -80,7 +80,7 @@ hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRec
                               const BvhDevice &bvh, const float4 *tex, const Targets &tg)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
-    const dim3 grid((fp.width + 31u) / 32u, (fp.row_end - fp.row_begin + 7u) / 8u);
+    const dim3 grid((fp.width + 31u) / 32u, band_strips(fp));
     const size_t fixed = (size_t)bvh.stack_depth * 256u * 4u;
     const size_t node_bytes = (size_t)bvh.n_nodes * sizeof(BvhNode4);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
@@ -98,13 +98,15 @@ template <bool AUX>
 __global__ void __launch_bounds__(256)
 k_wf_resolve(const FrameParams p, const Targets tg, WfBuffers wf)
 {
-    // a workgroup = 64 x 4 pixels: one row of 64 per wave, whole 512-byte pieces of every plane
-    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), ly = blockIdx.y * 4u + (threadIdx.x >> 6), y = p.row_begin + ly;
+    // a workgroup = 64 x 4 pixels (half a tile of the band's strip blockIdx.y / 2): one row of 64 per wave, whole 512-byte pieces
+    // of every plane
+    const uint32_t strip = blockIdx.y >> 1, in_strip = (blockIdx.y & 1u) * 4u + (threadIdx.x >> 6);
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = p.row_begin + strip * p.row_pitch + in_strip;
     if (x >= p.width || y >= p.row_end) return;
     const uint32_t pixel = y * p.width + x;
     if (wf.tile_live) {   // a piece of a tile nothing can be seen through (k_wf_classify): its sums were never touched
-        const uint32_t live = wf.tile_live[(ly / kWfTileH) * wf.tiles_x + blockIdx.x];
-        const uint32_t piece = ((ly >> 2) & 1u) * 2u + ((threadIdx.x >> 5) & 1u);
+        const uint32_t live = wf.tile_live[strip * wf.tiles_x + blockIdx.x];
+        const uint32_t piece = (blockIdx.y & 1u) * 2u + ((threadIdx.x >> 5) & 1u);
         if (!((live >> piece) & 1u)) {
             reinterpret_cast<uint32_t *>(tg.color)[pixel] = 0u;
             if (AUX) reinterpret_cast<float4 *>(tg.color_f32)[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -125,7 +127,7 @@ k_wf_resolve(const FrameParams p, const Targets tg, WfBuffers wf)
 hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
-    const dim3 grid((fp.width + 63u) / 64u, (fp.row_end - fp.row_begin + 3u) / 4u);
+    const dim3 grid((fp.width + 63u) / 64u, 2u * band_strips(fp));
     if (fp.flags & RWR_FLAG_AUX_OUTPUTS) hipLaunchKernelGGL((k_wf_resolve<true>), grid, dim3(256), 0, s, fp, tg, wf);
     else hipLaunchKernelGGL((k_wf_resolve<false>), grid, dim3(256), 0, s, fp, tg, wf);
     return hipGetLastError();

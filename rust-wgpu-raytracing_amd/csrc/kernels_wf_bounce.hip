@@ -280,7 +280,7 @@ RWR_DEV void add_contribution(TraceShared &sh, uint32_t e, float cr, float cg, f
 // share the pool, in whatever order, the sums are the same bits).  Call after a barrier.
 RWR_DEV void flush_pool(TraceShared &sh, const FrameParams &p, const WfBuffers &wf, uint32_t tile)
 {
-    const uint32_t tile_x0 = (tile % wf.tiles_x) * kWfTileW, tile_y0 = p.row_begin + (tile / wf.tiles_x) * kWfTileH;
+    const uint32_t tile_x0 = (tile % wf.tiles_x) * kWfTileW, tile_y0 = p.row_begin + (tile / wf.tiles_x) * p.row_pitch;
     const size_t plane = (size_t)p.width * p.height;   // (planes 0..2: red, green, blue; plane 3 is the primary stage's alpha)
     for (uint32_t q = threadIdx.x; q < kWfTilePixels; q += 256u) {
         const uint32_t px = tile_x0 + (q & (kWfTileW - 1u)), py = tile_y0 + q / kWfTileW;

@@ -154,7 +154,7 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
     }
     const uint32_t blk_x0 = bx * kWfTileW;
     const uint32_t tile_x0 = blk_x0 + (wave & 1u) * 32u;
-    const uint32_t tile_y0 = row_begin + by * kWfTileH + (wave >> 1) * 4u;
+    const uint32_t tile_y0 = row_begin + by * p.row_pitch + (wave >> 1) * 4u;
     const uint32_t px0 = tile_x0 + 2u * (lane & 15u), py = tile_y0 + (lane >> 4);
     constexpr float kTileWf = 32.0f, kTileHf = 4.0f;
     const bool in0 = py < p.row_end && px0 < p.width, in1 = in0 && (px0 + 1u < p.width);
@@ -163,7 +163,7 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
 
     // candidate faces of this wave's tile: rwr_wf_cull.h (shared with k_wf_classify)
     const WfWaveCull wc = wf_wave_cull<CULL>(ftris, n_tris, row_begin, bins_enabled, mesh_x0, mesh_y0, mesh_x1, mesh_y1, p.bins, blk_x0,
-                                             row_begin + by * kWfTileH, wave, lane);
+                                             row_begin + by * p.row_pitch, wave, lane);
     const uint32_t n_src = wc.n_src;
     const uint32_t *__restrict__ src = wc.src;
     const float tx0 = (float)tile_x0, ty0 = (float)tile_y0;
@@ -388,7 +388,7 @@ hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriReco
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0 || sample_count == 0) return hipSuccess;
     z_split = std::max(1u, std::min(z_split, sample_count));
-    const dim3 grid((fp.width + kWfTileW - 1u) / kWfTileW, (fp.row_end - fp.row_begin + kWfTileH - 1u) / kWfTileH, z_split);
+    const dim3 grid((fp.width + kWfTileW - 1u) / kWfTileW, band_strips(fp), z_split);
     const dim3 block(256);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0, do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
 #define RWR_WF_ARGS ftris, fp.n_tris, fp.row_begin, fp.bins.enabled, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], \
@@ -431,7 +431,7 @@ k_wf_classify(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     if (threadIdx.x == 0u) s_live = 0u;
     __syncthreads();
-    const uint32_t blk_x0 = blockIdx.x * kWfTileW, blk_y0 = row_begin + blockIdx.y * kWfTileH;
+    const uint32_t blk_x0 = blockIdx.x * kWfTileW, blk_y0 = row_begin + blockIdx.y * p.row_pitch;
     const uint32_t tile_x0 = blk_x0 + (wave & 1u) * 32u, tile_y0 = blk_y0 + (wave >> 1) * 4u;
     const WfWaveCull wc = wf_wave_cull<true>(ftris, n_tris, row_begin, bins_enabled, mesh_x0, mesh_y0, mesh_x1, mesh_y1, p.bins, blk_x0,
                                              blk_y0, wave, lane);
@@ -461,7 +461,7 @@ hipError_t launch_wf_classify(hipStream_t s, const FrameParams &fp, const FrameT
                               uint32_t *live_list, uint32_t *live_count, uint32_t *tile_live)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
-    const dim3 grid(tiles_x, (fp.row_end - fp.row_begin + kWfTileH - 1u) / kWfTileH);
+    const dim3 grid(tiles_x, band_strips(fp));
 #define RWR_WF_CLASSIFY(A) hipLaunchKernelGGL((k_wf_classify<A>), grid, dim3(256), 0, s, ftris, fp.n_tris, fp.row_begin, fp.bins.enabled, \
         fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tg, tiles_x, live_list, live_count, tile_live)
     if (fp.flags & RWR_FLAG_AUX_OUTPUTS) RWR_WF_CLASSIFY(true); else RWR_WF_CLASSIFY(false);

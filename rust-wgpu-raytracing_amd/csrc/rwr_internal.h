@@ -135,12 +135,15 @@ struct BinGrid {
     uint32_t bins_x, bins_y, capacity, enabled;
 };
 constexpr uint32_t kBinNoList = 0xffffffffu;
+constexpr uint32_t kStripRows = 8;   // rows of a strip = of every render kernel's workgroup tile (RWR_STRIP_ROWS)
 
 struct FrameParams {
     rwr_camera_inv_uniform cam;
     BinGrid bins;
     uint32_t width, height;       // full frame
-    uint32_t row_begin, row_end;  // band rendered by this launch
+    uint32_t row_begin, row_end;  // band rendered by this launch ...
+    uint32_t row_pitch;           // ... in 8-row strips: strip k of the launch starts at row_begin + k * row_pitch (8: every row of the
+                                  // band; 8 N: every N-th strip — the interleaved partition of a multi-GPU frame, rwr_render_strips)
     uint32_t n_spheres;
     uint32_t n_tris;
     uint32_t tex_w, tex_h;
@@ -175,6 +178,9 @@ struct FrameParams {
     uint32_t pad_m;
     const TangentRec *tangents;   // per face (RWR_FLAG_NORMAL_MAP)
 };
+// 8-row strips a launch renders (the y extent of every render kernel's grid)
+inline uint32_t band_strips(const FrameParams &fp) { return fp.row_end > fp.row_begin ? (fp.row_end - fp.row_begin + fp.row_pitch - 1u) / fp.row_pitch : 0u; }
+
 
 // context.cpp: records the calling thread's error message, returns `code`.
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));

@@ -1,4 +1,4 @@
-"""Frame partition across GPUs: N contiguous row bands, one process
+"""Frame partition across GPUs: N contiguous row bands — or every N-th strip of 8 rows — one process
 per GPU, and ONE gather of the finished bands to rank 0 (RCCL over xGMI on the GPU
 box; the same code runs over gloo in the CPU tests).  Pixels are independent, the
 scene is replicated, and ranks address pixels / key the RNG by GLOBAL coordinates,
@@ -11,6 +11,18 @@ def band_rows(rank: int, world: int, height: int) -> tuple[int, int]:
     if not (0 <= rank < world):
         raise ValueError(f"rank {rank} outside world {world}")
     return (rank * height) // world, ((rank + 1) * height) // world
+
+
+STRIP_ROWS = 8   # RWR_STRIP_ROWS: rows of a strip = of every render kernel's workgroup tile
+
+
+def strip_rows(rank: int, world: int, height: int) -> list[int]:
+    """Rows of the INTERLEAVED partition (rwr_render_strips(ctx, ..., rank, world)): strips rank, rank + world, ... of 8 rows.
+    Every rank gets the same share of whatever part of the screen the scene covers."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    return [y for s in range(rank, (height + STRIP_ROWS - 1) // STRIP_ROWS, world)
+            for y in range(s * STRIP_ROWS, min(height, (s + 1) * STRIP_ROWS))]
 
 
 def make_gather_list(frame_flat, world: int, width: int, height: int, bytes_per_pixel: int):

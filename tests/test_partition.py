@@ -22,6 +22,25 @@ def test_band_rows_tile_the_frame(rwr):
         band_rows(2, 2, 10)
 
 
+def test_strip_rows_tile_the_frame(rwr):
+    """The interleaved partition: every row belongs to exactly one rank, strips are 8 rows, shares differ by one strip."""
+    import rwr_amd.partition as part
+    for height in (1080, 2160, 70, 7, 8, 9, 1):
+        for world in (1, 2, 3, 8):
+            owner = np.full(height, -1)
+            sizes = []
+            for r in range(world):
+                rows = part.strip_rows(r, world, height)
+                assert all(owner[y] == -1 for y in rows)
+                owner[rows] = r
+                sizes.append(len(rows))
+                assert all((y // part.STRIP_ROWS) % world == r for y in rows)
+            assert (owner >= 0).all()
+            assert max(sizes) - min(sizes) <= part.STRIP_ROWS
+    with pytest.raises(ValueError):
+        part.strip_rows(2, 2, 100)
+
+
 def test_library_band_partition_is_the_same(rwr):
     """rwr_dist_band (what rwr_dist_gather_rgba8 uses for every rank's band) == partition.band_rows (what the gloo
     rehearsal below assembles with)."""
