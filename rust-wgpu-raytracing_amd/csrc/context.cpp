@@ -1001,16 +1001,17 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
         }
         // Did the frame before show LITTLE — fewer than 1 024 live tiles, and at most half of this frame's tiles (a small mesh
         // on an empty screen; not a small frame full of geometry, such as a row band of a multi-GPU frame: measured, that one
-        // is best left alone)?  Its count arrives through pinned memory, a frame late, never waited for.  Then up to 8
-        // workgroups share a tile's samples in the primary stage, and the tiles anything can be seen through are listed
-        // first (below).  Any choice gives the same frame: all sums are integers.
+        // is best left alone)?  Its count arrives through pinned memory, a frame late, never waited for.  Then several
+        // workgroups share a tile's samples in the primary stage (enough of them to fill the chip twice, up to one per
+        // sample), and the tiles anything can be seen through are listed first (below).  Any choice gives the same frame: all
+        // sums are integers.
         const uint32_t live = ctx->h_wf_live ? ctx->h_wf_live[0] + ctx->h_wf_live[1] : 0u;
         const bool shows_little = live != 0u && live < 1024u && 2u * live <= n_tiles;
         uint32_t z_split = ctx->wf_z_split;
         if (z_split == 0u) {
             z_split = 1u;
             if (shows_little)
-                while (z_split < 8u && z_split * live < 2048u) z_split *= 2u;
+                while (z_split < kWfMaxGroup && z_split * live < 2048u) z_split *= 2u;
         }
         // queue q: its half of every per-group buffer and its set of four counters (the primary stage zeroes the set it
         // is about to fill).  With one queue the frame's sums are read-modify-written by the tile's only workgroup; with
