@@ -67,6 +67,10 @@ def test_interleaved_strips_assemble_bit_identically(rwr, suzanne, height):
                 for k in asm:
                     assert np.array_equal(asm[k].view(np.uint8), full[k].view(np.uint8)), (n, k)
                 assert (primary, bounce) == (primary_full, bounce_full)
+        for params in (rwr.make_params(), rwr.make_params(spp=3, max_bounces=1)):
+            ctx.render(cam_inv, params, strips=(h // 8 + 3, h // 8 + 5))  # a rank beyond the frame's last strip renders nothing
+            ctx.synchronize()
+            assert ctx.last_render_stats() == (0, 0)
         with pytest.raises(rwr.RwrError):
             ctx.render(cam_inv, rwr.make_params(), strips=(2, 2))     # first strip must be below the stride
         with pytest.raises(rwr.RwrError):
