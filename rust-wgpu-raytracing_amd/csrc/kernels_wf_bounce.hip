@@ -328,8 +328,13 @@ RWR_DEV bool next_item(TraceShared &sh, const PoolInfo *__restrict__ info, uint3
 // Pools that are sparse or spread out (silhouette tiles, distant instances): one ray per lane, per-lane BVH
 // traversal with the nodelets and the traversal stacks in LDS (rwr_bvh.h).
 // STACK16: 16-bit traversal stack entries (rwr_bvh.h) for scenes of at most 4 095 faces and 32 767 nodes.
+#ifdef RWR_LANE_OCC   // (6 waves per SIMD: 80 VGPRs + 92 B of scratch, measured below)
+#define RWR_LANE_BOUNDS __launch_bounds__(256, RWR_LANE_OCC)
+#else
+#define RWR_LANE_BOUNDS __launch_bounds__(256)
+#endif
 template <bool NODES_IN_LDS, bool NMAP, bool STACK16>
-__global__ void __launch_bounds__(256)
+__global__ void RWR_LANE_BOUNDS
 k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
                 const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf, const PoolInfo *__restrict__ info,
                 uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list, uint32_t n_tiles)
