@@ -39,7 +39,11 @@ def per_frame(cfg):
 
 counters = {"_note": "per-step (= per-frame) sums over the kernels of one frame, from rocprofv3 --kernel-trace --pmc passes (tools/pmc2.sh, "
                      "one counter group per run; per-launch means x launches per frame); FETCH_SIZE doubled on gfx950 (64 B counted per "
-                     "128-B read request), WRITE_SIZE taken as reported (MI355X_MICROARCH.md HBM section); KB -> bytes x 1024"}
+                     "128-B read request: MI355X_MICROARCH.md HBM section) EXCEPT for the trace kernels' gather of 32-byte ray records at "
+                     "random slots, which the guide leaves uncalibrated and tools/ubench/gather32.hip calibrated (profiles/"
+                     "r02_gather_calibration.txt: FETCH_SIZE = 64 B per 32-byte record read, i.e. one sub-line request per record, counted "
+                     "once: not doubled); WRITE_SIZE taken as reported; KB -> bytes x 1024"}
+GATHER_KERNELS = ("k_wf_trace_packet", "k_wf_trace_lane")   # FETCH_SIZE counts their requests whole (see _note)
 CFGS = ("cfg2", "cfg2b", "cfg3", "cfg4", "cfg5")
 for cfg in CFGS:
     p = pmc(cfg)
@@ -48,7 +52,7 @@ for cfg in CFGS:
         per = {k: 1.0 for k in kernels}
     else:
         per = per_frame(cfg)
-    tot = {"SQ_ACTIVE_INST_VALU": 0.0, "SQ_INSTS_VALU": 0.0, "FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0}
+    tot = {"SQ_ACTIVE_INST_VALU": 0.0, "SQ_INSTS_VALU": 0.0, "FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0, "FETCH_BYTES": 0.0}
     detail = {}
     for k in kernels:
         n = per.get(k, 0.0)
@@ -59,8 +63,10 @@ for cfg in CFGS:
             if name in c:
                 d[key] = c[name][0]
                 tot[key] += c[name][0] * n
+                if name == "FETCH_SIZE":
+                    tot["FETCH_BYTES"] += c[name][0] * n * 1024.0 * (1.0 if any(g in k for g in GATHER_KERNELS) else 2.0)
         detail[k] = d
-    traffic = int((2.0 * tot["FETCH_SIZE_KB"] + tot["WRITE_SIZE_KB"]) * 1024)
+    traffic = int(tot["FETCH_BYTES"] + tot["WRITE_SIZE_KB"] * 1024)
     counters[cfg] = {"source": f"profiles/r02_pmc_{cfg}_summary.txt", **{k: round(v, 1) for k, v in tot.items()},
                      "traffic_bytes_per_step": traffic, "kernels": detail}
 json.dump(counters, open(os.path.join(DST, "r02_counters.json"), "w"), indent=1)
