@@ -523,17 +523,33 @@ k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const
     const size_t pool_base = (size_t)tile * wf.group * kWfTilePixels;
     const uint16_t *__restrict__ sorted = wf.sorted + pool_base;
 
-    for (;;) {
+    // A wave always holds its NEXT packet too: which one it is, and the slots of its rays — requested while the current packet
+    // is traversed, so that a packet begins with one memory round trip (the ray records), not three in a row.
+    struct Packet { uint32_t pk, oct, first, last, e0, e1; };
+    auto grab = [&]() {
+        Packet q;
         uint32_t pk = 0;
         if (lane == 0u) pk = atomicAdd(&sh.next_packet, 1u);
-        pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk) * n_shares + share;   // this workgroup's share of the packets
-        if (pk >= n_packets) break;
-        uint32_t oct = 0;
+        q.pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk) * n_shares + share;   // this workgroup's share of the packets
+        q.oct = 0; q.first = 0; q.last = 0; q.e0 = 0; q.e1 = 0;
+        if (q.pk < n_packets) {   // uniform
+            uint32_t oct = 0;
 #pragma unroll
-        for (int o = 1; o < 8; o++) oct += (pk >= sh.pk_begin[o]) ? 1u : 0u;
-        oct = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct);
-        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sh.oct_begin[oct] + (pk - sh.pk_begin[oct]) * 128u));
-        const uint32_t last = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.oct_begin[oct + 1]);
+            for (int o = 1; o < 8; o++) oct += (q.pk >= sh.pk_begin[o]) ? 1u : 0u;
+            q.oct = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct);
+            q.first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sh.oct_begin[q.oct] + (q.pk - sh.pk_begin[q.oct]) * 128u));
+            q.last = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.oct_begin[q.oct + 1]);
+            const uint32_t i0 = q.first + lane, i1 = q.first + 64u + lane;
+            q.e0 = sorted[i0 < q.last ? i0 : q.first];
+            q.e1 = sorted[i1 < q.last ? i1 : q.first];
+        }
+        return q;
+    };
+    Packet next = grab();
+    for (;;) {
+        const Packet cur_pk = next;
+        if (cur_pk.pk >= n_packets) break;
+        const uint32_t oct = cur_pk.oct, first = cur_pk.first, last = cur_pk.last;
         // Gray-coded octant -> sign bits (rwr_device.h wf_direction_bin): sz = bit 2, sy = bit 1 ^ sz, sx = bit 0 ^ sy
         const uint32_t sz = oct >> 2, sy = ((oct >> 1) & 1u) ^ sz, sx = (oct & 1u) ^ sy;
 
@@ -541,9 +557,10 @@ k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const
         const uint32_t i0 = first + lane, i1 = first + 64u + lane;
         PairRays R;
         R.valid = i2{i0 < last ? -1 : 0, i1 < last ? -1 : 0};
-        const uint32_t e0 = R.valid.x ? sorted[i0] : sorted[first], e1 = R.valid.y ? sorted[i1] : sorted[first];
+        const uint32_t e0 = cur_pk.e0, e1 = cur_pk.e1;
         const float4 a0 = wf.rays[2u * (pool_base + e0)], b0 = wf.rays[2u * (pool_base + e0) + 1u];   // one 32-byte record per ray
         const float4 a1 = wf.rays[2u * (pool_base + e1)], b1 = wf.rays[2u * (pool_base + e1) + 1u];
+        next = grab();
         R.O = v3{f2{a0.x, a1.x}, f2{a0.y, a1.y}, f2{a0.z, a1.z}};
         R.D = v3{f2{b0.x, b1.x}, f2{b0.y, b1.y}, f2{b0.z, b1.z}};
         const v3 thr = v3{f2{wf_unorm16_lo(a0.w), wf_unorm16_lo(a1.w)}, f2{wf_unorm16_hi(a0.w), wf_unorm16_hi(a1.w)},
