@@ -54,13 +54,13 @@ CONFIGS = {
                  camera=dict(eye=(0, 0, 0), target=(0, 0, -1)),
                  label="cube.obj 256x256 1spp primary rays (configs[0])"),
     # BASELINE.json configs[2..4]: the wavefront integrator (extensions; parity cases, not the headline)
-    "cfg3": dict(scene="suzanne_lowpoly.obj", width=1920, height=1080, spp=64, bounces=1, steps=20, warmup=2,
+    "cfg3": dict(scene="suzanne_lowpoly.obj", width=1920, height=1080, spp=64, bounces=1, steps=20, warmup=4,
                  camera=dict(eye=(0, 0, 0), target=(0, 0, -1)),
                  label="suzanne_lowpoly.obj 1920x1080 64spp + 1 diffuse bounce, wavefront (configs[2])"),
-    "cfg4": dict(scene="suzanne_lowpoly.obj", width=3840, height=2160, spp=16, bounces=1, instances=4, steps=10, warmup=2,
+    "cfg4": dict(scene="suzanne_lowpoly.obj", width=3840, height=2160, spp=16, bounces=1, instances=4, steps=20, warmup=4,
                  camera=dict(eye=(0, 0, 12), target=(0, 0, -1)),
                  label="suzanne_lowpoly.obj x16 instanced 3840x2160 16spp + 1 bounce, BVH (configs[3])"),
-    "cfg5": dict(scene="suzanne_lowpoly.obj", width=3840, height=2160, spp=64, bounces=1, instances=4, steps=5, warmup=1,
+    "cfg5": dict(scene="suzanne_lowpoly.obj", width=3840, height=2160, spp=64, bounces=1, instances=4, steps=10, warmup=4,
                  camera=dict(eye=(0, 0, 12), target=(0, 0, -1)),
                  label="suzanne_lowpoly.obj x16 instanced 3840x2160 64spp + 1 bounce (configs[4])"),
 }
@@ -172,10 +172,11 @@ def main() -> int:
 
     # Frames in flight: like a swapchain, the context owns two sets of targets and alternates between
     # them, so one frame's kernel ramps up while the previous frame's last waves drain (at 1080p about
-    # 40 % of a lone frame kernel is its first and last waves' latency chain).  With a
-    # gather the root has one receive buffer, and wavefront frames share one accumulator: 1.
+    # 40 % of a lone frame kernel is its first and last waves' latency chain; a slot also owns a set of the
+    # wavefront integrator's accumulators and ray queues, so its frames overlap the same way).  With a gather the root has one
+    # receive buffer: 1.
     primary_only = cfg["spp"] == 1 and cfg["bounces"] == 0
-    fif = args.frames_in_flight if args.frames_in_flight else (2 if (primary_only and not use_dist) else 1)
+    fif = args.frames_in_flight if args.frames_in_flight else (1 if use_dist else 2)
     ctx.set_frames_in_flight(fif)
 
     render = ctx.render_call(cam_inv, params, strips=(rank, world)) if use_dist else ctx.render_call(cam_inv, params, rows=(0, h))
@@ -195,7 +196,7 @@ def main() -> int:
     # here, before the warm-up steps, like the scene upload and the BVH build: setup, not a step.
     clk = ctx.measure_valu_clock(8)
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup):   # (wavefront configs: at least one frame per slot, or a slot's queues are allocated inside the timed region)
         step()
     torch.cuda.synchronize()
     barrier()
@@ -232,8 +233,8 @@ def main() -> int:
     serial_ms_per_frame, serial_kernel_us = None, None
     if fif > 1:
         ctx.set_frames_in_flight(1)
-        n_serial = max(50, min(500, args.steps // 4))
-        for _ in range(10):
+        n_serial = max(50, min(500, args.steps // 4)) if primary_only else max(3, min(20, args.steps))
+        for _ in range(10 if primary_only else 1):
             step()
         ctx.set_kernel_timing(max(1, n_serial // 64))
         ctx.timer_begin()

@@ -126,30 +126,46 @@ struct rwr_context {
     uint32_t wf_min_packet_pools = 128;   // tunable: RWR_WF_MIN_PACKET_POOLS
     float aabb_lo[3] = {0, 0, 0}, aabb_hi[3] = {0, 0, 0};   // of the (flattened) world-space faces
     float auto_bvh_face_px = 150.0f;   // tunable: RWR_AUTO_BVH_FACE_PX (0 = never pick the BVH kernel by itself)
-    // wavefront integrator state
-    DeviceBuffer<float4> d_rays;
-    bool wf_fix_clean = false;      // the fixed-point planes are all zero (k_wf_resolve leaves them so)
+    // wavefront integrator: tunables and what the host remembers of the last frame
     uint32_t *h_wf_live = nullptr;  // pinned: live pools of the last launch group {packets, per-lane}, read a frame late
     uint32_t wf_z_split = 0;        // tunable: RWR_WF_ZSPLIT (0 = from the previous frame's live pools)
-    DeviceBuffer<unsigned long long> d_wf_masks;
-    DeviceBuffer<uint16_t> d_wf_sorted, d_wf_bins;
-    DeviceBuffer<uint32_t> d_wave_total;
-    DeviceBuffer<unsigned long long> d_wf_fix;   // fixed-point bounce sums, 3 planes
-    DeviceBuffer<uint8_t> d_pool_info;
-    DeviceBuffer<uint32_t> d_wf_live;            // device counters of the bounce stage, a set of four per ray queue
-    DeviceBuffer<uint32_t> d_pool_list;          // live pools by class, 2 x tiles
-    DeviceBuffer<uint32_t> d_wf_tiles;           // frames that show little: live tile list, per-tile live pieces, the count (k_wf_classify)
     DeviceBuffer<unsigned long long> d_wf_dbg;   // RWR_WF_STATS=1: pool classification counters, printed at destroy
     uint32_t wf_group = 32;         // samples per launch group; tunable: RWR_WF_GROUP (1..32)
     float wf_packet_fill = 0.25f;   // pools filled at least this much are traced as packets; tunable: RWR_WF_PACKET_FILL (> 1: never)
     uint32_t last_segments = 0;     // tiles of the last wavefront frame
-    // Launch groups alternate between the frame's stream and this one, each with its own half of the ray queue: the
-    // latency-bound ends of one group (the sort, the last packets) run beside the other group's arithmetic.
+    uint32_t last_wf_state = 0;     // ... and whose accumulators and queues it used
     static constexpr uint32_t kWfMaxQueues = 4;
-    hipStream_t wf_streams[kWfMaxQueues] = {};   // [0] unused: queue 0 runs on the frame's stream
-    hipEvent_t wf_fork = nullptr, wf_join[kWfMaxQueues] = {};
     uint32_t wf_queues = 2;         // tunable: RWR_WF_OVERLAP (1 puts every launch group on the frame's stream; measured at
                                     // configs[2] / [4]: two queues -6.5 % / -9.5 %, three and four less, a staggered start less)
+    // The integrator's device state, one set per frame slot: a frame of the integrator then shares nothing with the frames in
+    // the other slots (they overlap like reference frames do), and reuses its own set in stream order.
+    struct WfState {
+        DeviceBuffer<float4> d_rays;
+        bool fix_clean = false;         // the fixed-point planes are all zero (k_wf_resolve leaves them so)
+        DeviceBuffer<unsigned long long> d_masks;
+        DeviceBuffer<uint16_t> d_sorted, d_bins;
+        DeviceBuffer<uint32_t> d_wave_total;
+        DeviceBuffer<unsigned long long> d_fix;   // the frame's fixed-point sums, 4 planes
+        DeviceBuffer<uint8_t> d_pool_info;
+        DeviceBuffer<uint32_t> d_live;            // device counters of the bounce stage, a set of four per ray queue
+        DeviceBuffer<uint32_t> d_pool_list;       // live pools by class, 2 x tiles
+        DeviceBuffer<uint32_t> d_tiles;           // frames that show little: live tile list, per-tile live pieces, the count (k_wf_classify)
+        // Launch groups alternate between the frame's stream and these, each with its own part of the ray queue: the
+        // latency-bound ends of one group (the sort, the last packets) run beside the other group's arithmetic.
+        hipStream_t streams[kWfMaxQueues] = {};   // [0] unused: queue 0 runs on the frame's stream
+        hipEvent_t fork = nullptr, join[kWfMaxQueues] = {};
+        void release()
+        {
+            for (uint32_t q = 0; q < kWfMaxQueues; q++) {
+                if (streams[q]) { (void)hipStreamSynchronize(streams[q]); (void)hipStreamDestroy(streams[q]); streams[q] = nullptr; }
+                if (join[q]) { (void)hipEventDestroy(join[q]); join[q] = nullptr; }
+            }
+            if (fork) { (void)hipEventDestroy(fork); fork = nullptr; }
+            d_rays.release(); d_masks.release(); d_sorted.release(); d_bins.release(); d_wave_total.release(); d_fix.release();
+            d_pool_info.release(); d_live.release(); d_pool_list.release(); d_tiles.release();
+            fix_clean = false;
+        }
+    } wf_state[kMaxFramesInFlight];
     uint32_t last_spp = 0;
     bool last_had_bounce = false;
     // one decoded texture per scene part (texels decoded to linear f32 at upload, Rgba8UnormSrgb semantics)
@@ -526,12 +542,8 @@ void rwr_ctx_destroy(rwr_context *ctx)
     ctx->d_tris.release(); ctx->d_shade.release(); ctx->d_cull.release(); ctx->d_tangent.release();
     for (auto &t : ctx->d_nmaps) t.release();
     ctx->d_bvh_nodes.release(); ctx->d_bvh_leaf_faces.release();
-    for (uint32_t q = 0; q < rwr_context::kWfMaxQueues; q++) {
-        if (ctx->wf_streams[q]) { (void)hipStreamSynchronize(ctx->wf_streams[q]); (void)hipStreamDestroy(ctx->wf_streams[q]); ctx->wf_streams[q] = nullptr; }
-        if (ctx->wf_join[q]) { (void)hipEventDestroy(ctx->wf_join[q]); ctx->wf_join[q] = nullptr; }
-    }
-    if (ctx->wf_fork) { (void)hipEventDestroy(ctx->wf_fork); ctx->wf_fork = nullptr; }
-    ctx->d_rays.release(); if (ctx->h_wf_live) { (void)hipHostFree(ctx->h_wf_live); ctx->h_wf_live = nullptr; } ctx->d_wf_masks.release(); ctx->d_wf_sorted.release(); ctx->d_wf_bins.release(); ctx->d_wave_total.release(); ctx->d_wf_fix.release(); ctx->d_pool_info.release(); ctx->d_wf_live.release(); ctx->d_pool_list.release(); ctx->d_wf_tiles.release(); for (auto &t : ctx->d_texs) t.release();
+    for (auto &w : ctx->wf_state) w.release();
+    if (ctx->h_wf_live) { (void)hipHostFree(ctx->h_wf_live); ctx->h_wf_live = nullptr; } for (auto &t : ctx->d_texs) t.release();
     ctx->d_face_mat.release(); ctx->d_materials.release();
     for (FrameSlot &sl : ctx->slots) {
         sl.release_buffers();
@@ -808,13 +820,11 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
     const bool aux = (rp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
     int rc = rebuild_tris(ctx);
     if (rc != RWR_OK) return rc;
-    // Frame slot: the next one in turn.  A frame of the wavefront integrator uses the context's single
-    // accumulator and ray queue, so it first waits for the frame before it (milliseconds of work: nothing
-    // to gain from overlap), and so does the frame after it.
-    const uint32_t prev = ctx->cur;
+    // Frame slot: the next one in turn.  A slot owns everything a frame writes — targets, per-frame records, and for the
+    // wavefront integrator a whole set of accumulators and ray queues (WfState) — so frames in different slots share
+    // nothing and a slot is reused in stream order.
     ctx->cur = (ctx->cur + 1u) % ctx->n_slots;
     FrameSlot &sl = ctx->slots[ctx->cur];
-    if (ctx->n_slots > 1u && (wavefront || ctx->last_spp != 0u)) RWR_HIP_CHECK(hipStreamSynchronize(ctx->slots[prev].stream));
     const hipStream_t stream = sl.stream;
     if (aux) {
         // a band render leaves the rest of the planes untouched: they start zeroed, like the targets
@@ -964,35 +974,36 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
         // wavefront integrator: the samples are traced in launch groups; per group the primary stage (all of the
         // group's samples of every pixel, rays into the fixed-slot queue) then the bounce stage (one workgroup per
         // 64x8-pixel tile and its ray pool)
+        rwr_context::WfState &W = ctx->wf_state[ctx->n_slots > 1u ? ctx->cur : 0u];   // this slot's accumulators and queues
         const uint32_t group = std::min(rp.spp, ctx->wf_group);
         const uint32_t tiles_x = (ctx->screen.width + kWfTileW - 1u) / kWfTileW, tiles_y = band_strips(fp);
         const uint32_t n_tiles = tiles_x * tiles_y;
-        RWR_HIP_CHECK(ctx->d_wave_total.ensure((size_t)n_tiles * 4u));
-        RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wave_total.ptr, 0, (size_t)n_tiles * 4u * sizeof(uint32_t), stream));
-        if (ctx->d_wf_fix.count < 4u * n) ctx->wf_fix_clean = false;
-        RWR_HIP_CHECK(ctx->d_wf_fix.ensure(4u * n));
-        if (!ctx->wf_fix_clean)   // first use, a new size, or a frame that did not reach its resolve
-            RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wf_fix.ptr, 0, 4u * n * sizeof(unsigned long long), stream));
-        ctx->wf_fix_clean = false;
+        RWR_HIP_CHECK(W.d_wave_total.ensure((size_t)n_tiles * 4u));
+        RWR_HIP_CHECK(hipMemsetAsync(W.d_wave_total.ptr, 0, (size_t)n_tiles * 4u * sizeof(uint32_t), stream));
+        if (W.d_fix.count < 4u * n) W.fix_clean = false;
+        RWR_HIP_CHECK(W.d_fix.ensure(4u * n));
+        if (!W.fix_clean)   // first use, a new size, or a frame that did not reach its resolve
+            RWR_HIP_CHECK(hipMemsetAsync(W.d_fix.ptr, 0, 4u * n * sizeof(unsigned long long), stream));
+        W.fix_clean = false;
         // two launch groups in flight (each on its own stream, with its own half of the queue) when the frame has several
         const size_t n_queues = rp.max_bounces ? std::min<size_t>(ctx->wf_queues, (rp.spp + group - 1u) / group) : 1u;
         const bool overlap = n_queues > 1u;
         const size_t slots = (size_t)n_tiles * group * kWfTilePixels;
         if (rp.max_bounces) {
-            RWR_HIP_CHECK(ctx->d_rays.ensure(n_queues * 2u * slots));
-            RWR_HIP_CHECK(ctx->d_wf_sorted.ensure(n_queues * slots));
-            RWR_HIP_CHECK(ctx->d_wf_bins.ensure(n_queues * slots));
-            RWR_HIP_CHECK(ctx->d_wf_masks.ensure(n_queues * n_tiles * group * 8u));
-            RWR_HIP_CHECK(ctx->d_pool_info.ensure(n_queues * n_tiles * wf_pool_info_bytes()));
-            RWR_HIP_CHECK(ctx->d_pool_list.ensure(n_queues * 2u * (size_t)n_tiles));
-            if (overlap && !ctx->wf_fork) RWR_HIP_CHECK(hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming));
+            RWR_HIP_CHECK(W.d_rays.ensure(n_queues * 2u * slots));
+            RWR_HIP_CHECK(W.d_sorted.ensure(n_queues * slots));
+            RWR_HIP_CHECK(W.d_bins.ensure(n_queues * slots));
+            RWR_HIP_CHECK(W.d_masks.ensure(n_queues * n_tiles * group * 8u));
+            RWR_HIP_CHECK(W.d_pool_info.ensure(n_queues * n_tiles * wf_pool_info_bytes()));
+            RWR_HIP_CHECK(W.d_pool_list.ensure(n_queues * 2u * (size_t)n_tiles));
+            if (overlap && !W.fork) RWR_HIP_CHECK(hipEventCreateWithFlags(&W.fork, hipEventDisableTiming));
             for (size_t q = 0; q < n_queues; q++) {
-                if (q && !ctx->wf_streams[q]) RWR_HIP_CHECK(hipStreamCreateWithFlags(&ctx->wf_streams[q], hipStreamNonBlocking));
-                if (q && !ctx->wf_join[q]) RWR_HIP_CHECK(hipEventCreateWithFlags(&ctx->wf_join[q], hipEventDisableTiming));
+                if (q && !W.streams[q]) RWR_HIP_CHECK(hipStreamCreateWithFlags(&W.streams[q], hipStreamNonBlocking));
+                if (q && !W.join[q]) RWR_HIP_CHECK(hipEventCreateWithFlags(&W.join[q], hipEventDisableTiming));
             }
-            if (!ctx->d_wf_live.ptr) {
-                RWR_HIP_CHECK(ctx->d_wf_live.ensure(4u * rwr_context::kWfMaxQueues));
-                RWR_HIP_CHECK(hipMemsetAsync(ctx->d_wf_live.ptr, 0, 4u * rwr_context::kWfMaxQueues * sizeof(uint32_t), stream));
+            if (!W.d_live.ptr) {
+                RWR_HIP_CHECK(W.d_live.ensure(4u * rwr_context::kWfMaxQueues));
+                RWR_HIP_CHECK(hipMemsetAsync(W.d_live.ptr, 0, 4u * rwr_context::kWfMaxQueues * sizeof(uint32_t), stream));
             }
             if (!ctx->h_wf_live) {
                 RWR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_wf_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
@@ -1020,49 +1031,50 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
         // through; the primary stage, the sort and the resolve then touch those alone.  Same frame either way.
         uint32_t *live_list = nullptr, *live_count = nullptr, *tile_live = nullptr;
         if (z_split > 1u && (shows_little || ctx->wf_z_split != 0u) && !(rp.flags & RWR_FLAG_NO_CULL)) {   // (a forced split: the tests' way in)
-            RWR_HIP_CHECK(ctx->d_wf_tiles.ensure(2u * (size_t)n_tiles + 1u));
-            live_list = ctx->d_wf_tiles.ptr; tile_live = live_list + n_tiles; live_count = tile_live + n_tiles;
+            RWR_HIP_CHECK(W.d_tiles.ensure(2u * (size_t)n_tiles + 1u));
+            live_list = W.d_tiles.ptr; tile_live = live_list + n_tiles; live_count = tile_live + n_tiles;
             RWR_HIP_CHECK(hipMemsetAsync(live_count, 0, sizeof(uint32_t), stream));
             RWR_HIP_CHECK(launch_wf_classify(stream, fp, sl.d_ftris.ptr, tg, tiles_x, live_list, live_count, tile_live));
         }
         WfBuffers wfq[rwr_context::kWfMaxQueues];
         for (size_t q = 0; q < n_queues; q++) {
             const size_t h = q;
-            wfq[q] = WfBuffers{ctx->d_wf_fix.ptr,
-                               ctx->d_rays.ptr ? ctx->d_rays.ptr + h * 2u * slots : nullptr,
-                               ctx->d_wf_masks.ptr ? ctx->d_wf_masks.ptr + h * n_tiles * group * 8u : nullptr,
-                               ctx->d_wf_bins.ptr ? ctx->d_wf_bins.ptr + h * slots : nullptr,
-                               ctx->d_wf_sorted.ptr ? ctx->d_wf_sorted.ptr + h * slots : nullptr,
-                               ctx->d_wave_total.ptr, group, tiles_x, ctx->d_wf_dbg.ptr,
-                               rp.max_bounces ? ctx->d_wf_live.ptr + h * 4u : nullptr, overlap ? 1u : 0u, live_list, live_count, tile_live};
+            wfq[q] = WfBuffers{W.d_fix.ptr,
+                               W.d_rays.ptr ? W.d_rays.ptr + h * 2u * slots : nullptr,
+                               W.d_masks.ptr ? W.d_masks.ptr + h * n_tiles * group * 8u : nullptr,
+                               W.d_bins.ptr ? W.d_bins.ptr + h * slots : nullptr,
+                               W.d_sorted.ptr ? W.d_sorted.ptr + h * slots : nullptr,
+                               W.d_wave_total.ptr, group, tiles_x, ctx->d_wf_dbg.ptr,
+                               rp.max_bounces ? W.d_live.ptr + h * 4u : nullptr, overlap ? 1u : 0u, live_list, live_count, tile_live};
         }
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u,
                             ctx->wf_packet_extent * ctx->bvh_leaf_extent, ctx->wf_min_packet_pools};
         if (overlap) {   // the other streams start behind this frame's setup (and so behind the previous frame's resolve)
-            RWR_HIP_CHECK(hipEventRecord(ctx->wf_fork, stream));
-            for (size_t q = 1; q < n_queues; q++) RWR_HIP_CHECK(hipStreamWaitEvent(ctx->wf_streams[q], ctx->wf_fork, 0));
+            RWR_HIP_CHECK(hipEventRecord(W.fork, stream));
+            for (size_t q = 1; q < n_queues; q++) RWR_HIP_CHECK(hipStreamWaitEvent(W.streams[q], W.fork, 0));
         }
         for (uint32_t s0 = 0, g = 0; s0 < rp.spp; s0 += group, g++) {
             const uint32_t cnt = std::min(group, rp.spp - s0);
             const size_t q = g % n_queues;
-            hipStream_t gs = q ? ctx->wf_streams[q] : stream;
+            hipStream_t gs = q ? W.streams[q] : stream;
             RWR_HIP_CHECK(launch_wf_primary(gs, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0, tg, wfq[q], s0, cnt, z_split));
             if (rp.max_bounces) {
                 RWR_HIP_CHECK(launch_wf_bounce(gs, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh, tex0, wfq[q], n_tiles, cnt,
                                                (uint32_t)std::fmax(1.0f, std::ceil(ctx->wf_packet_fill * (float)(cnt * kWfTilePixels))),
-                                               ctx->d_pool_info.ptr + q * n_tiles * wf_pool_info_bytes(), ctx->d_pool_list.ptr + q * 2u * (size_t)n_tiles));
+                                               W.d_pool_info.ptr + q * n_tiles * wf_pool_info_bytes(), W.d_pool_list.ptr + q * 2u * (size_t)n_tiles));
                 if (s0 + group >= rp.spp)   // the last group's live-pool counts, for the next frame's split
                     RWR_HIP_CHECK(hipMemcpyAsync(ctx->h_wf_live, wfq[q].counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, gs));
             }
         }
         for (size_t q = 1; q < n_queues; q++) {
-            RWR_HIP_CHECK(hipEventRecord(ctx->wf_join[q], ctx->wf_streams[q]));
-            RWR_HIP_CHECK(hipStreamWaitEvent(stream, ctx->wf_join[q], 0));
+            RWR_HIP_CHECK(hipEventRecord(W.join[q], W.streams[q]));
+            RWR_HIP_CHECK(hipStreamWaitEvent(stream, W.join[q], 0));
         }
         RWR_HIP_CHECK(launch_wf_resolve(stream, fp, tg, wfq[0]));
-        ctx->wf_fix_clean = true;   // (the resolve zeroes what it reads; rows outside the band were never touched)
+        W.fix_clean = true;   // (the resolve zeroes what it reads; rows outside the band were never touched)
         ctx->last_spp = rp.spp;
         ctx->last_segments = n_tiles;
+        ctx->last_wf_state = ctx->n_slots > 1u ? ctx->cur : 0u;
         ctx->last_had_bounce = rp.max_bounces != 0;
     }
     if (time_this) {
@@ -1330,7 +1342,7 @@ int rwr_last_render_stats(rwr_context *ctx, uint64_t *primary_rays, uint64_t *bo
         DeviceGuard g(ctx->device);
         std::vector<uint32_t> counts((size_t)ctx->last_segments * 4u);   // per tile and wave of the primary stage
         RWR_HIP_CHECK(hipStreamSynchronize(ctx->slots[ctx->cur].stream));
-        RWR_HIP_CHECK(hipMemcpy(counts.data(), ctx->d_wave_total.ptr, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        RWR_HIP_CHECK(hipMemcpy(counts.data(), ctx->wf_state[ctx->last_wf_state].d_wave_total.ptr, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         ctx->last_bounce = 0;
         for (uint32_t c : counts) ctx->last_bounce += c;
     }

@@ -28,7 +28,7 @@ def test_frames_in_flight_give_the_same_frames(rwr, gpu_ctx, suzanne):
                 gpu_ctx.render(c, rwr.make_params())
             got = gpu_ctx.readback()
             assert np.array_equal(got["color"], want[-1]["color"]) and np.array_equal(got["depth"], want[-1]["depth"])
-            # a path-traced frame between primary frames (shared accumulator: it must wait for its neighbours)
+            # a path-traced frame between primary frames (its slot's own accumulators and queues)
             gpu_ctx.render(cams[1], rwr.make_params())
             gpu_ctx.render(cams[0], rwr.make_params(spp=2, max_bounces=1, seed=3))
             pt = gpu_ctx.readback()
@@ -44,6 +44,43 @@ def test_frames_in_flight_give_the_same_frames(rwr, gpu_ctx, suzanne):
         gpu_ctx.set_frames_in_flight(0)
     with pytest.raises(rwr.RwrError):
         gpu_ctx.set_frames_in_flight(4)
+
+
+@pytest.mark.gpu
+def test_path_traced_frames_in_flight_give_the_same_frames(rwr, suzanne):
+    """A frame slot owns a whole set of the wavefront integrator's accumulators and ray queues: path-traced frames queued
+    back to back in two or three slots (different cameras, sample counts, with and without a bounce, reference frames in
+    between) are each the frame a single-slot context renders — the one read last, and every one when read one by one."""
+    w, h = 200, 96
+    seq = [((0, 0, 0), 5, 1), ((0, 0, 3), 3, 1), ((1.5, 0.5, 2.5), 1, 0), ((0, 1, 4), 4, 0), ((0.2, 0, 2.8), 40, 1), ((0, 0, 3), 2, 1),
+           ((0, 0, 0), 1, 0), ((1, 1, 3), 6, 1)]
+    frames = [(rwr.camera_build_inv_uniform(rwr.make_camera(eye=e, aspect=w / h)), rwr.make_params(spp=spp, max_bounces=b, seed=7, flags=rwr.FLAG_AUX_OUTPUTS))
+              for e, spp, b in seq]
+    with rwr.Context(0) as ctx:
+        ctx.upload_model(suzanne); ctx.set_spheres(rwr.make_spheres()); ctx.resize(w, h)
+        want = []
+        for cam, params in frames:
+            ctx.render(cam, params)
+            want.append(ctx.readback(aux=True))
+        for n in (2, 3):
+            ctx.set_frames_in_flight(n)
+            for rounds in range(2):                     # the second round reuses every slot's buffers
+                for i, (cam, params) in enumerate(frames):   # read one by one
+                    ctx.render(cam, params)
+                    got = ctx.readback(aux=True)
+                    for k in ("color", "depth", "obj_id", "hit_t", "color_f32"):
+                        assert np.array_equal(got[k].view(np.uint8), want[i][k].view(np.uint8)), (n, i, k)
+            for upto in (3, 5, len(frames)):            # queue several, read the last
+                for cam, params in frames[:upto]:
+                    ctx.render(cam, params)
+                got = ctx.readback(aux=True)
+                for k in ("color", "depth", "obj_id", "hit_t", "color_f32"):
+                    assert np.array_equal(got[k].view(np.uint8), want[upto - 1][k].view(np.uint8)), (n, upto, k)
+            ctx.resize(w + 8, h)                        # a resize in between: every slot's buffers follow
+            ctx.resize(w, h)
+        ctx.set_frames_in_flight(1)
+        ctx.render(*frames[0])
+        assert np.array_equal(ctx.readback()["color"], want[0]["color"])
 
 
 @pytest.mark.gpu
