@@ -1170,7 +1170,9 @@ int rwr_ctx_set_frames_in_flight(rwr_context *ctx, uint32_t n)
         if (i == 0) continue;
         ctx->slots[i].release_buffers();
         ctx->slots[i].aux_valid = false;
+        ctx->wf_state[i].release();   // (gigabytes of ray queue when the slot rendered path-traced frames)
     }
+    if (ctx->last_wf_state >= n) { ctx->last_wf_state = 0; ctx->last_segments = 0; ctx->last_spp = 0; }
     // the most recent frame stays where it is if its slot survives, otherwise it is gone
     ctx->n_slots = n;
     if (ctx->cur >= n) ctx->cur = 0;
