@@ -21,13 +21,17 @@ with r.Context(0) as a, r.Context(0) as b:
         a.set_frames_in_flight(1); b.set_frames_in_flight(fif)
         cams = [r.camera_build_inv_uniform(r.make_camera(eye=tuple(rng.uniform(-4, 4, 3)), target=tuple(rng.uniform(-1, 1, 3)), aspect=w / h))
                 for _ in range(12)]
+        # a mix of reference frames and path-traced ones (a slot owns a set of the integrator's accumulators and queues)
+        params = [r.make_params() if rng.random() < 0.4 else
+                  r.make_params(spp=int(rng.integers(1, 40)), max_bounces=int(rng.integers(0, 2)), seed=int(rng.integers(0, 1000)))
+                  for _ in cams]
         want = []
-        for c in cams:
-            a.render(c, r.make_params())
+        for c, pr in zip(cams, params):
+            a.render(c, pr)
             want.append(a.readback())
         # b: queue a burst, read the last; then read every frame after queuing the next one(s)
         for i, c in enumerate(cams):
-            b.render(c, r.make_params())
+            b.render(c, params[i])
             if rng.random() < 0.5 or i == len(cams) - 1:
                 got = b.readback()
                 assert np.array_equal(got["color"], want[i]["color"]) and np.array_equal(got["depth"], want[i]["depth"]), (w, h, fif, i)
