@@ -325,7 +325,7 @@ def main() -> int:
         hbm = {"achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 5),
                "algorithmic_bytes_per_step": algo_bytes}
         if not primary_only_cfg:
-            n_groups = -(-cfg["spp"] // 32)   # launch groups of 32 samples
+            n_groups = -(-cfg["spp"] // (64 if fif > 1 else 32))   # launch groups: 64 samples with frames in flight, else 32
             design = int(float(bounce_rays) * (2 * 32 + 2 * 2 + 2 * 2) + w * my_rows * (n_groups * 7 * 16 + 4 * 16 + 4))
             hbm.update({"design_bytes_per_step": design, "design_frac": round(design / launch_s / 1e9 / HBM_PEAK_GBS, 5),
                         "traffic_frac": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 5) if traffic else None})

@@ -130,7 +130,10 @@ struct rwr_context {
     uint32_t *h_wf_live = nullptr;  // pinned: live pools of the last launch group {packets, per-lane}, read a frame late
     uint32_t wf_z_split = 0;        // tunable: RWR_WF_ZSPLIT (0 = from the previous frame's live pools)
     DeviceBuffer<unsigned long long> d_wf_dbg;   // RWR_WF_STATS=1: pool classification counters, printed at destroy
-    uint32_t wf_group = 32;         // samples per launch group; tunable: RWR_WF_GROUP (1..32)
+    uint32_t wf_group = 0;          // samples per launch group; tunable: RWR_WF_GROUP (1..64); 0: 32 for a context that renders one
+                                    // frame at a time (a 64-spp frame's two groups overlap each other on two queues), 64 with frames in
+                                    // flight (larger pools sort into tighter packets; the overlap comes from the other frame): measured
+                                    // at configs[2], two slots: 8.55 -> 8.21 ms per frame; one slot: 8.81 -> 8.98
     float wf_packet_fill = 0.25f;   // pools filled at least this much are traced as packets; tunable: RWR_WF_PACKET_FILL (> 1: never)
     uint32_t last_segments = 0;     // tiles of the last wavefront frame
     uint32_t last_wf_state = 0;     // ... and whose accumulators and queues it used
@@ -975,7 +978,7 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
         // group's samples of every pixel, rays into the fixed-slot queue) then the bounce stage (one workgroup per
         // 64x8-pixel tile and its ray pool)
         rwr_context::WfState &W = ctx->wf_state[ctx->n_slots > 1u ? ctx->cur : 0u];   // this slot's accumulators and queues
-        const uint32_t group = std::min(rp.spp, ctx->wf_group);
+        const uint32_t group = std::min(rp.spp, ctx->wf_group ? ctx->wf_group : (ctx->n_slots > 1u ? 64u : 32u));
         const uint32_t tiles_x = (ctx->screen.width + kWfTileW - 1u) / kWfTileW, tiles_y = band_strips(fp);
         const uint32_t n_tiles = tiles_x * tiles_y;
         RWR_HIP_CHECK(W.d_wave_total.ensure((size_t)n_tiles * 4u));

@@ -704,6 +704,14 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
     // well-filled, compact pools: packet traversal (its one stack is a VGPR of 64 entries)
     const bool packets = bvh.stack_depth <= 64u && packet_min_rays <= sample_count * kWfTilePixels && bvh.packet_extent > 0.0f;
     const size_t sort_lds = 2u * (size_t)sample_count * kWfTilePixels * sizeof(uint16_t);
+    if (sort_lds > 64u * 1024u) {   // beyond the default limit of dynamic LDS (groups of more than 32 samples)
+        static const hipError_t raised = [] {
+            const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            return a != hipSuccess ? a : b;
+        }();
+        if (raised != hipSuccess) return raised;
+    }
     if (wf.live_list)
         hipLaunchKernelGGL(k_wf_sort<true>, dim3(std::min(n_tiles, 2048u)), dim3(kWfSortThreads), sort_lds, s, wf, info, counters, pool_list, n_tiles,
                            sample_count, packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);

@@ -201,7 +201,11 @@ hipError_t launch_prebake(hipStream_t s, const rwr_model_vertex_small *verts, co
 // [0, 1]) travels as unorm16, which moves a colour by at most 8e-6 of the second hit's radiance.  masks[(tile * group + s) * 8 + wave * 2 + k] = ballot of the
 // lanes that emitted.  The bounce stage compacts a pool by those ballots while sorting it by direction.
 constexpr uint32_t kWfTileW = 64, kWfTileH = 8, kWfTilePixels = kWfTileW * kWfTileH;
-constexpr uint32_t kWfMaxGroup = 32;          // samples per launch group (LDS of the bounce stage is sized for it)
+#ifndef RWR_WF_MAX_GROUP
+#define RWR_WF_MAX_GROUP 64
+#endif
+constexpr uint32_t kWfMaxGroup = RWR_WF_MAX_GROUP;   // samples per launch group at most (the sort's LDS: 4 B per ray of a pool = 128 KiB at 64;
+                                                     // the primary stage's 32-bit sums: a sample's term saturates at 2^10 / kWfMaxGroup)
 constexpr float kWfFixedScale = 67108864.0f;  // 2^26: a term < 64, thousands of them < 2^64
 #ifndef RWR_WF_CELL_BITS
 #define RWR_WF_CELL_BITS 3

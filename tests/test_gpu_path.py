@@ -234,3 +234,24 @@ def test_live_tile_list_without_a_bounce(rwr, orc, suzanne):
             os.environ["RWR_WF_ZSPLIT"] = saved
     for k in ("color", "color_f32", "depth", "obj_id", "hit_t"):
         assert np.array_equal(frames[0][k].view(np.uint8), frames[1][k].view(np.uint8)), k
+
+
+def test_launch_groups_of_64_samples(rwr, orc, suzanne):
+    """A context with frames in flight traces 64 samples per launch group (one queue, larger pools); one that renders a frame
+    at a time 32 (two queues).  70 spp: groups of 64 + 6 against 32 + 32 + 6 — the same bytes, and the oracle's frame."""
+    w, h, spp = 136, 40, 70
+    cam_inv = rwr.camera_build_inv_uniform(rwr.make_camera(eye=(0.2, 0.1, 2.2), aspect=w / h))
+    params = rwr.make_params(spp=spp, max_bounces=1, seed=5, flags=rwr.FLAG_AUX_OUTPUTS)
+    want = orc.render_path(cam_inv.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), orc.make_params(spp, 1, seed=5),
+                           orc.make_spheres(), suzanne)
+    frames = []
+    for slots in (1, 2):
+        with rwr.Context(0) as ctx:
+            ctx.set_frames_in_flight(slots)
+            frames.append(_gpu(rwr, ctx, suzanne, rwr.make_spheres(), cam_inv, w, h, params))
+            again = _gpu(rwr, ctx, suzanne, rwr.make_spheres(), cam_inv, w, h, params)     # the other slot
+            for k in ("color", "color_f32", "depth", "obj_id", "hit_t"):
+                assert np.array_equal(frames[-1][k].view(np.uint8), again[k].view(np.uint8)), (slots, k)
+        _check(frames[-1], want, spp)
+    for k in ("color", "color_f32", "depth", "obj_id", "hit_t"):
+        assert np.array_equal(frames[0][k].view(np.uint8), frames[1][k].view(np.uint8)), k
