@@ -108,6 +108,9 @@ def main() -> int:
     ap.add_argument("--frames-in-flight", type=int, default=None,
                     help="target sets / streams the context alternates between (default: 2 for the single-GPU "
                          "frame kernel, 1 with a gather or the wavefront integrator)")
+    ap.add_argument("--skip-serial", action="store_true",
+                    help="leave out the one-frame-at-a-time segment after the timed region (profiling runs: every frame of the "
+                         "process then runs the same schedule)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the gather path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
@@ -231,7 +234,7 @@ def main() -> int:
     # (b) the same frames one at a time (no overlap between frames): the latency of a frame and the
     #     duration of a lone kernel launch
     serial_ms_per_frame, serial_kernel_us = None, None
-    if fif > 1:
+    if fif > 1 and not args.skip_serial:
         ctx.set_frames_in_flight(1)
         n_serial = max(50, min(500, args.steps // 4)) if primary_only else max(3, min(20, args.steps))
         for _ in range(10 if primary_only else 1):

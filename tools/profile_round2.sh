@@ -21,12 +21,12 @@ fi
 k() { name=$1; shift; timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -- python3 bench.py --cpu-seconds 0 "$@" > $O/trace_$name.log 2>&1; cp $O/trace_$name/*/*kernel_stats.csv $O/kernel_stats_$name.csv; }
 k cfg2 --steps 500 --warmup 100
 k cfg2_one_in_flight --steps 500 --warmup 100 --frames-in-flight 1
-k cfg3 --config cfg3 --steps 3 --warmup 1
-k cfg4 --config cfg4 --steps 10 --warmup 2
-k cfg5 --config cfg5 --steps 5 --warmup 2
+k cfg3 --config cfg3 --steps 4 --warmup 2 --skip-serial
+k cfg4 --config cfg4 --steps 10 --warmup 2 --skip-serial
+k cfg5 --config cfg5 --steps 5 --warmup 2 --skip-serial
 tools/pmc2.sh $O/pmc_cfg2 "--steps 200 --warmup 20" inst cyc fetch write > $O/pmc_cfg2.txt 2>&1
 tools/pmc2.sh $O/pmc_cfg2b "--config cfg2b --steps 200 --warmup 20" inst cyc fetch write > $O/pmc_cfg2b.txt 2>&1
-tools/pmc2.sh $O/pmc_cfg3 "--config cfg3 --steps 1 --warmup 1" inst cyc fetch write > $O/pmc_cfg3.txt 2>&1
-tools/pmc2.sh $O/pmc_cfg4 "--config cfg4 --steps 3 --warmup 2" inst cyc fetch write > $O/pmc_cfg4.txt 2>&1
-tools/pmc2.sh $O/pmc_cfg5 "--config cfg5 --steps 2 --warmup 2" inst cyc fetch write > $O/pmc_cfg5.txt 2>&1
+tools/pmc2.sh $O/pmc_cfg3 "--config cfg3 --steps 2 --warmup 2 --skip-serial" inst cyc fetch write > $O/pmc_cfg3.txt 2>&1
+tools/pmc2.sh $O/pmc_cfg4 "--config cfg4 --steps 3 --warmup 2 --skip-serial" inst cyc fetch write > $O/pmc_cfg4.txt 2>&1
+tools/pmc2.sh $O/pmc_cfg5 "--config cfg5 --steps 2 --warmup 2 --skip-serial" inst cyc fetch write > $O/pmc_cfg5.txt 2>&1
 ls $O | head -50
