@@ -11,7 +11,7 @@
 // when the frame fills the chip by itself, up to 32 when only a few tiles see the mesh — otherwise four waves
 // would chew through thousands of rays while 250 CUs idle.
 //                  1. compaction + sort, in one: the ballots the primary stage published say which fixed queue
-//                     slots hold a ray; every ray's direction is binned (octant x 8x8 cells of the octahedral map,
+//                     slots hold a ray; every ray's direction is binned (octant x 16x16 cells of the octahedral map,
 //                     Morton order inside an octant), a histogram / prefix sum / scatter through LDS atomics
 //                     leaves the pool's live slots in direction order (wf.sorted, 2 B per ray).
 //                     Rays of one wave then start from almost the same point in almost the same direction:
@@ -84,8 +84,7 @@ RWR_DEV uint32_t pool_split(uint32_t live, bool packets)
 
 struct SortShared {
     unsigned long long masks[kWfMaxGroup * 8u];
-    uint32_t hist[kWfDirBins];
-    uint32_t offs[kWfDirBins];
+    uint32_t hist[kWfDirBins];   // rays per direction bin, then (in place) where the bin's next ray goes in the sorted list
     uint32_t lo[3], hi[3];   // bounds of the ray origins of the group's first samples (order-preserving keys)
     uint32_t wave_sum[4];
     uint32_t total;
@@ -200,7 +199,7 @@ RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, co
             for (uint32_t w = 0; w < (tid >> 6); w++) before += sh.wave_sum[w];
             if ((tid & 31u) == 0u) info[tile].oct_begin[tid >> 5] = before;   // octant o begins at bin (kWfDirBins / 8) o = kPer * (32 o)
 #pragma unroll
-            for (uint32_t k = 0; k < kPer; k++) { sh.offs[kPer * tid + k] = before; before += c[k]; }
+            for (uint32_t k = 0; k < kPer; k++) { sh.hist[kPer * tid + k] = before; before += c[k]; }   // (its own bins: in place)
         }
     }
     if (tid == 0u) {
@@ -221,7 +220,7 @@ RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, co
     uint16_t *s_sorted = s_bins + n_slots;
     for (uint32_t e = tid; e < n_slots; e += NT) {
         const uint32_t bin = s_bins[e];
-        if (bin != 0xffffu) s_sorted[atomicAdd(&sh.offs[bin], 1u)] = (uint16_t)e;
+        if (bin != 0xffffu) s_sorted[atomicAdd(&sh.hist[bin], 1u)] = (uint16_t)e;
     }
     __syncthreads();
     uint4 *__restrict__ out = reinterpret_cast<uint4 *>(wf.sorted + pool_base);   // pool_base is a multiple of 512

@@ -208,10 +208,11 @@ constexpr uint32_t kWfMaxGroup = RWR_WF_MAX_GROUP;   // samples per launch group
                                                      // the primary stage's 32-bit sums: a sample's term saturates at 2^10 / kWfMaxGroup)
 constexpr float kWfFixedScale = 67108864.0f;  // 2^26: a term < 64, thousands of them < 2^64
 #ifndef RWR_WF_CELL_BITS
-#define RWR_WF_CELL_BITS 3
+#define RWR_WF_CELL_BITS 4
 #endif
 constexpr uint32_t kWfDirCellBits = RWR_WF_CELL_BITS;                 // cells per side of an octant of the octahedral map, log2
-constexpr uint32_t kWfDirBins = 8u << (2u * kWfDirCellBits);   // 8 octants x 8x8 cells (16x16 measured slower: the sort loses more than the packets gain)
+constexpr uint32_t kWfDirBins = 8u << (2u * kWfDirCellBits);   // 8 octants x 16x16 cells (8x8: +6 % at configs[2] — coarser packets; the sort keeps its
+                                                               // counts and offsets in ONE LDS array, or the finer histogram costs it its occupancy)
 struct WfBuffers {
     unsigned long long *fix;       // 4 planes of W*H: the frame's radiance sums as 2^-26 FIXED POINT — red, green, blue of
                                    // E(h0) + albedo(h0) * E(h1) over all samples, and alpha (2 per primary hit).  Integer sums are
