@@ -235,6 +235,7 @@ RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, co
 #endif
 constexpr uint32_t kWfSortThreads = RWR_SORT_THREADS;   // (a pool's sort is all latency; on whole frames 256 and 1024 measure the same — the
                                                         // sort hides behind the other queue — on a band of 510 pools 1024 is 3x faster)
+static_assert(kWfSortThreads >= kWfMaxGroup * 8u && kWfSortThreads >= 256u, "one thread per ballot word of a pool; the prefix sum needs four waves");
 template <bool LIST>
 __global__ void __launch_bounds__(kWfSortThreads)
 k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list,
