@@ -294,17 +294,45 @@ RWR_API int rwr_dist_get_unique_id(uint8_t id[RWR_DIST_ID_BYTES]);
 RWR_API int rwr_dist_init(rwr_context *ctx, int rank, int world, const uint8_t id[RWR_DIST_ID_BYTES]);
 /* The band partition every rank must use: rows [rank*H/world, (rank+1)*H/world). */
 RWR_API int rwr_dist_band(uint32_t rank, uint32_t world, uint32_t height, uint32_t *row_begin, uint32_t *row_end);
-/* Collective, asynchronous (stream-ordered after the frame rendered last). */
+/* Collective, asynchronous (stream-ordered after the frame rendered last).  Every frame slot
+ * (rwr_ctx_set_frames_in_flight) owns its own message / receive / frame buffers, so the gather of one frame runs beside
+ * the render of the next; the RCCL exchanges themselves stay in call order. */
 RWR_API int rwr_dist_gather_rgba8(rwr_context *ctx, int root);
 /* The same for the interleaved partition (every rank rendered rwr_render_strips(ctx, ..., rank, world)): each rank packs
- * its strips into one message, the root deals the received strips out into the frame.  One grouped exchange per frame. */
+ * its strips into one message (one launch), the root deals the received strips out into the frame (one launch).  One
+ * grouped exchange per frame. */
 RWR_API int rwr_dist_gather_strips_rgba8(rwr_context *ctx, int root);
-/* Root only: device address of the assembled W*H*4 frame / copy to the host (waits for the gather). */
+/* Root only: device address of the assembled W*H*4 frame gathered last / copy to the host (waits for that gather).  With
+ * several frames in flight the address alternates between the slots' buffers. */
 RWR_API int rwr_dist_frame(rwr_context *ctx, void **d_rgba8);
 RWR_API int rwr_dist_readback(rwr_context *ctx, uint8_t *rgba8);
 /* Collective: returns when every rank's frames in flight have finished (an all-reduce of one word). */
 RWR_API int rwr_dist_barrier(rwr_context *ctx);
 RWR_API int rwr_dist_destroy(rwr_context *ctx);
+
+/* The layout of the interleaved partition's gather, as the library itself uses it (csrc/rwr_strips.h) — for a host that
+ * wants to size buffers or exchange the messages by other means.  Rank `rank` of `world` owns `strips` strips of the
+ * frame's `n_strips` (strip s belongs to rank s % world); its message is those strips back to back, `rows` rows
+ * (a short last strip of the frame ends the message of the rank that owns it: owns_tail); in the root's receive buffer
+ * (`recv_rows_total` rows) that message starts at row `recv_row` (messages start on whole-strip boundaries). */
+typedef struct rwr_strip_layout {
+    uint32_t n_strips, strips, rows, recv_row, recv_rows_total, owns_tail;
+} rwr_strip_layout;
+RWR_API int rwr_dist_strip_layout(uint32_t rank, uint32_t world, uint32_t height, rwr_strip_layout *out);
+/* Pack and deal-out on HOST memory by the same layout (byte moves only; the render path stays on the GPU): for a host
+ * that stages the exchange through CPU memory, and for the world-size-2/3 tests that run over gloo without a GPU.
+ * message: rank's strips back to back (8 * strips rows of capacity); recv: recv_rows_total rows. */
+RWR_API int rwr_dist_host_pack_strips(uint32_t rank, uint32_t world, uint32_t width, uint32_t height,
+                                      const uint8_t *frame_rgba8, uint8_t *message);
+RWR_API int rwr_dist_host_deal_strips(uint32_t world, uint32_t width, uint32_t height, const uint8_t *recv, uint8_t *frame_rgba8);
+/* Self-test of the gather's own stages on ONE GPU for any world size, no communicator: the context plays every rank in
+ * turn.  After rendering rank's share (rwr_render_strips(ctx, ..., rank, world), or rwr_render_rows of rwr_dist_band
+ * with strips = 0) _deposit runs that rank's side of the gather on the frame just rendered — the same pack launch, message
+ * size and receive address as rwr_dist_gather_[strips_]rgba8 — with a device copy in place of the ncclSend/ncclRecv
+ * pair; after the last rank _finish runs the root's deal-out.  rwr_dist_readback / rwr_dist_frame then return the frame
+ * a root would hold. */
+RWR_API int rwr_dist_loopback_deposit(rwr_context *ctx, uint32_t rank, uint32_t world, int strips);
+RWR_API int rwr_dist_loopback_finish(rwr_context *ctx, uint32_t world, int strips);
 
 /* hipEvent timing on the stream(s) the kernels are launched on: rwr_timer_begin waits until nothing
  * is in flight and records; rwr_timer_end joins every frame in flight into the end event. */

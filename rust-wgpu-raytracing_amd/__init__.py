@@ -115,6 +115,9 @@ def lib() -> C.CDLL:
         "rwr_dist_get_unique_id": [vp], "rwr_dist_init": [vp, i32, i32, vp], "rwr_dist_band": [u32, u32, u32, vp, vp],
         "rwr_dist_gather_rgba8": [vp, i32], "rwr_dist_gather_strips_rgba8": [vp, i32], "rwr_dist_frame": [vp, vp], "rwr_dist_readback": [vp, vp],
         "rwr_dist_barrier": [vp], "rwr_dist_destroy": [vp],
+        "rwr_dist_strip_layout": [u32, u32, u32, vp], "rwr_dist_host_pack_strips": [u32, u32, u32, u32, vp, vp],
+        "rwr_dist_host_deal_strips": [u32, u32, u32, vp, vp],
+        "rwr_dist_loopback_deposit": [vp, u32, u32, i32], "rwr_dist_loopback_finish": [vp, u32, i32],
         "rwr_measure_valu_clock": [vp, u32, vp], "rwr_clock_probe_start": [vp, u32], "rwr_clock_probe_read": [vp, vp],
     }
     for name, argtypes in sigs.items():
@@ -281,6 +284,37 @@ def dist_band(rank: int, world: int, height: int) -> tuple[int, int]:
     a, b = C.c_uint32(), C.c_uint32()
     _check(lib().rwr_dist_band(rank, world, height, C.byref(a), C.byref(b)))
     return a.value, b.value
+
+
+class _StripLayout(C.Structure):   # rwr_strip_layout
+    _fields_ = [(n, C.c_uint32) for n in ("n_strips", "strips", "rows", "recv_row", "recv_rows_total", "owns_tail")]
+
+
+def dist_strip_layout(rank: int, world: int, height: int) -> dict:
+    """The interleaved partition's gather layout as the library uses it (rwr_dist_strip_layout; host arithmetic, no GPU)."""
+    out = _StripLayout()
+    _check(lib().rwr_dist_strip_layout(rank, world, height, C.byref(out)))
+    return {n: int(getattr(out, n)) for n, _ in _StripLayout._fields_}
+
+
+def dist_host_pack_strips(rank: int, world: int, frame: np.ndarray) -> np.ndarray:
+    """rank's message (its strips back to back) cut from a whole (H, W, 4) uint8 frame in HOST memory, by the library's layout."""
+    frame = np.ascontiguousarray(frame, np.uint8)
+    h, w = frame.shape[:2]
+    lay = dist_strip_layout(rank, world, h)
+    msg = np.zeros((max(1, lay["strips"] * STRIP_ROWS), w, 4), np.uint8)
+    _check(lib().rwr_dist_host_pack_strips(rank, world, w, h, _p(frame), _p(msg)))
+    return msg[:lay["rows"]]
+
+
+def dist_host_deal_strips(world: int, recv: np.ndarray, height: int) -> np.ndarray:
+    """The frame assembled from the root's receive buffer ((recv_rows_total, W, 4) uint8, HOST memory), by the library's layout."""
+    recv = np.ascontiguousarray(recv, np.uint8)
+    w = recv.shape[1]
+    assert recv.shape[0] == dist_strip_layout(0, world, height)["recv_rows_total"]
+    frame = np.zeros((height, w, 4), np.uint8)
+    _check(lib().rwr_dist_host_deal_strips(world, w, height, _p(recv), _p(frame)))
+    return frame
 
 
 # ------------------------------------------------------------------------ context --
@@ -484,6 +518,13 @@ class Context:
                 _check(rc)
 
         return call
+
+    def dist_loopback_deposit(self, rank: int, world: int, strips: bool = True):
+        """One-GPU self-test of the gather: `rank`'s side on the frame just rendered, a device copy in place of Send/Recv."""
+        _check(lib().rwr_dist_loopback_deposit(self._h, rank, world, 1 if strips else 0))
+
+    def dist_loopback_finish(self, world: int, strips: bool = True):
+        _check(lib().rwr_dist_loopback_finish(self._h, world, 1 if strips else 0))
 
     def dist_readback(self) -> np.ndarray:
         out = np.zeros((self.height, self.width, 4), np.uint8)

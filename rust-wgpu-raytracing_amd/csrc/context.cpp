@@ -19,6 +19,7 @@
 
 #include "bvh.hpp"
 #include "rwr_internal.h"
+#include "rwr_strips.h"
 
 namespace rwr {
 
@@ -204,10 +205,21 @@ struct rwr_context {
     void *rccl_lib = nullptr;
     ncclComm_t comm = nullptr;
     int dist_rank = 0, dist_world = 0;
-    DeviceBuffer<uint8_t> d_gathered;    // root: the assembled RGBA8 frame
-    DeviceBuffer<uint8_t> d_strip_pack, d_strip_recv;   // interleaved partition: this rank's strips back to back; root: every rank's
-    hipEvent_t gather_done = nullptr;    // orders consecutive gathers that run on different frame slots' streams
-    bool gathered_valid = false;
+    // one gather set per frame slot: the gather of the frame in one slot shares nothing with the frame rendered next in another
+    struct GatherSet {
+        DeviceBuffer<uint8_t> d_gathered;       // root: the assembled RGBA8 frame
+        DeviceBuffer<uint8_t> d_pack, d_recv;   // interleaved partition: this rank's message; root: every rank's, side by side (rwr_strips.h)
+        hipEvent_t done = nullptr;              // the set's last gather has finished
+        bool valid = false;                     // d_gathered holds (or will hold, once `done`) a whole frame
+        void release()
+        {
+            d_gathered.release(); d_pack.release(); d_recv.release();
+            if (done) { (void)hipEventDestroy(done); done = nullptr; }
+            valid = false;
+        }
+    } gather[kMaxFramesInFlight];
+    uint32_t last_gather = 0;               // the set rwr_dist_frame / rwr_dist_readback refer to
+    hipEvent_t exchange_done = nullptr;     // orders the RCCL exchanges of consecutive frames (they run on different slots' streams)
     // shader-clock probe (rwr_clock_probe_start / _read): one spinning wave on its own stream
     hipStream_t probe_stream = nullptr;
     DeviceBuffer<ulonglong2> d_probe;
@@ -790,6 +802,7 @@ int rwr_resize(rwr_context *ctx, const rwr_screen *screen)
         RWR_HIP_CHECK(ensure_slot_targets(ctx, i));
         ctx->slots[i].aux_valid = false;
     }
+    for (rwr_context::GatherSet &gs : ctx->gather) gs.valid = false;   // a frame gathered at the old size is gone
     RWR_HIP_CHECK(ensure_frame_buffers(ctx));
     return RWR_OK;
 }
@@ -1174,7 +1187,9 @@ int rwr_ctx_set_frames_in_flight(rwr_context *ctx, uint32_t n)
         ctx->slots[i].release_buffers();
         ctx->slots[i].aux_valid = false;
         ctx->wf_state[i].release();   // (gigabytes of ray queue when the slot rendered path-traced frames)
+        ctx->gather[i].release();
     }
+    if (ctx->last_gather >= n) ctx->last_gather = 0;
     if (ctx->last_wf_state >= n) { ctx->last_wf_state = 0; ctx->last_segments = 0; ctx->last_spp = 0; }
     // the most recent frame stays where it is if its slot survives, otherwise it is gone
     ctx->n_slots = n;
@@ -1412,6 +1427,33 @@ int rwr_dist_band(uint32_t rank, uint32_t world, uint32_t height, uint32_t *row_
     return RWR_OK;
 }
 
+int rwr_dist_strip_layout(uint32_t rank, uint32_t world, uint32_t height, rwr_strip_layout *out)
+{
+    if (!out || world == 0u || rank >= world) return set_error(RWR_ERR_INVALID_ARGUMENT, "rank %u outside world %u", rank, world);
+    const StripLayout L = StripLayout::make(height, world);
+    out->n_strips = L.n_strips;
+    out->strips = L.strips_of(rank);
+    out->rows = L.rows_of(rank);
+    out->recv_row = L.recv_row(rank);
+    out->recv_rows_total = L.recv_rows_total();
+    out->owns_tail = L.owns_tail(rank) ? 1u : 0u;
+    return RWR_OK;
+}
+
+int rwr_dist_host_pack_strips(uint32_t rank, uint32_t world, uint32_t width, uint32_t height, const uint8_t *frame_rgba8, uint8_t *message)
+{
+    if (!frame_rgba8 || !message || world == 0u || rank >= world) return set_error(RWR_ERR_INVALID_ARGUMENT, "bad argument (rank %u, world %u)", rank, world);
+    strips_pack_host(StripLayout::make(height, world), rank, (size_t)width * 4u, frame_rgba8, message);
+    return RWR_OK;
+}
+
+int rwr_dist_host_deal_strips(uint32_t world, uint32_t width, uint32_t height, const uint8_t *recv, uint8_t *frame_rgba8)
+{
+    if (!frame_rgba8 || !recv || world == 0u) return set_error(RWR_ERR_INVALID_ARGUMENT, "bad argument (world %u)", world);
+    strips_deal_host(StripLayout::make(height, world), (size_t)width * 4u, recv, frame_rgba8);
+    return RWR_OK;
+}
+
 int rwr_dist_get_unique_id(uint8_t id[RWR_DIST_ID_BYTES])
 {
     if (!id) return set_error(RWR_ERR_INVALID_ARGUMENT, "id is NULL");
@@ -1437,120 +1479,222 @@ int rwr_dist_init(rwr_context *ctx, int rank, int world, const uint8_t id[RWR_DI
     RWR_NCCL_CHECK(g_rccl.CommInitRank(&ctx->comm, world, uid, rank));
     ctx->dist_rank = rank;
     ctx->dist_world = world;
-    if (!ctx->gather_done) RWR_HIP_CHECK(hipEventCreateWithFlags(&ctx->gather_done, hipEventDisableTiming));
     return RWR_OK;
 }
 
-int rwr_dist_gather_rgba8(rwr_context *ctx, int root)
+}  // extern "C"
+
+// ---- the gather, in stages --------------------------------------------------------------------------------------------
+// Every frame slot owns a *gather set* (message, receive buffer, assembled frame, completion event), so the gather of one
+// frame shares nothing with the frame rendered next in another slot: pack -> exchange -> deal-out of frame n run beside
+// the render of frame n + 1.  The stages below are what BOTH the RCCL gather and the one-GPU loopback self-test run; the two
+// differ in the exchange step alone (ncclSend/ncclRecv against a device copy to the same address).
+namespace {
+
+hipError_t gather_set_events(rwr_context *ctx, rwr_context::GatherSet &gs)
+{
+    if (!gs.done) return hipEventCreateWithFlags(&gs.done, hipEventDisableTiming);
+    return hipSuccess;
+}
+
+// -- interleaved strips
+int strips_stage_pack(rwr_context *ctx, rwr_context::GatherSet &gs, const FrameSlot &sl, const StripLayout &L, uint32_t me, hipStream_t stream)
+{
+    const uint32_t row_bytes = ctx->screen.width * 4u;
+    RWR_HIP_CHECK(gs.d_pack.ensure((size_t)std::max(1u, L.strips_of(me) * kStripRows) * row_bytes));
+    RWR_HIP_CHECK(launch_strips_pack(stream, L, me, row_bytes, sl.d_color.ptr, gs.d_pack.ptr));
+    return RWR_OK;
+}
+int strips_stage_root_buffers(rwr_context *ctx, rwr_context::GatherSet &gs, const StripLayout &L)
+{
+    const size_t row_bytes = (size_t)ctx->screen.width * 4u;
+    RWR_HIP_CHECK(gs.d_gathered.ensure(row_bytes * L.height));
+    RWR_HIP_CHECK(gs.d_recv.ensure(row_bytes * std::max(1u, L.recv_rows_total())));
+    return RWR_OK;
+}
+// where rank r's message lands in the root's receive buffer, and its size
+uint8_t *strips_recv_at(rwr_context *ctx, rwr_context::GatherSet &gs, const StripLayout &L, uint32_t r) { return gs.d_recv.ptr + (size_t)L.recv_row(r) * ctx->screen.width * 4u; }
+size_t strips_message_bytes(rwr_context *ctx, const StripLayout &L, uint32_t r) { return (size_t)L.rows_of(r) * ctx->screen.width * 4u; }
+int strips_stage_deal(rwr_context *ctx, rwr_context::GatherSet &gs, const StripLayout &L, hipStream_t stream)
+{
+    RWR_HIP_CHECK(launch_strips_deal(stream, L, ctx->screen.width * 4u, gs.d_recv.ptr, gs.d_gathered.ptr));
+    return RWR_OK;
+}
+
+// -- contiguous bands: they are sent from the frame and land in place, no pack, no deal-out
+void band_span(rwr_context *ctx, uint32_t r, uint32_t world, size_t *offset, size_t *bytes)
+{
+    uint32_t a = 0, b = 0;
+    (void)rwr_dist_band(r, world, ctx->screen.height, &a, &b);
+    const size_t row_bytes = (size_t)ctx->screen.width * 4u;
+    *offset = (size_t)a * row_bytes;
+    *bytes = (size_t)(b - a) * row_bytes;
+}
+
+// One grouped RCCL exchange: `send` (may be empty) to the root; on the root one receive per rank with a non-empty
+// message, at recv_at(r).  The group is closed on every path.
+template <typename RecvAt, typename RecvBytes>
+int rccl_gather_exchange(rwr_context *ctx, int root, const void *send, size_t send_bytes, RecvAt recv_at, RecvBytes recv_bytes, hipStream_t stream)
+{
+    ncclResult_t res = g_rccl.GroupStart();
+    if (res != ncclSuccess) return set_error(RWR_ERR_HIP, "ncclGroupStart failed: %s", g_rccl.GetErrorString(res));
+    if (send_bytes) res = g_rccl.Send(send, send_bytes, ncclUint8, root, ctx->comm, stream);
+    if (ctx->dist_rank == root)
+        for (int r = 0; r < ctx->dist_world && res == ncclSuccess; r++)
+            if (recv_bytes((uint32_t)r)) res = g_rccl.Recv(recv_at((uint32_t)r), recv_bytes((uint32_t)r), ncclUint8, r, ctx->comm, stream);
+    const ncclResult_t end = g_rccl.GroupEnd();   // also after a failed send / receive: a group must not stay open
+    if (res == ncclSuccess) res = end;
+    if (res != ncclSuccess) return set_error(RWR_ERR_HIP, "RCCL gather failed: %s", g_rccl.GetErrorString(res));
+    return RWR_OK;
+}
+
+int gather_checks(rwr_context *ctx, int root, bool need_comm)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
-    if (!ctx->comm) return set_error(RWR_ERR_NOT_READY, "rwr_dist_init has not been called");
-    if (root < 0 || root >= ctx->dist_world) return set_error(RWR_ERR_INVALID_ARGUMENT, "root %d outside world %d", root, ctx->dist_world);
+    if (need_comm) {
+        if (!ctx->comm) return set_error(RWR_ERR_NOT_READY, "rwr_dist_init has not been called");
+        if (root < 0 || root >= ctx->dist_world) return set_error(RWR_ERR_INVALID_ARGUMENT, "root %d outside world %d", root, ctx->dist_world);
+    }
     if (ctx->screen.width == 0) return set_error(RWR_ERR_NOT_READY, "rwr_resize has not been called");
+    return RWR_OK;
+}
+
+// Consecutive exchanges of one communicator run on different frame slots' streams: they are ordered among themselves
+// (RCCL operations of a communicator are issued in one order on every rank), the rest of a slot's work is not held back.
+int order_exchange_begin(rwr_context *ctx, hipStream_t stream)
+{
+    if (!ctx->exchange_done) RWR_HIP_CHECK(hipEventCreateWithFlags(&ctx->exchange_done, hipEventDisableTiming));
+    else if (ctx->n_slots > 1u) RWR_HIP_CHECK(hipStreamWaitEvent(stream, ctx->exchange_done, 0));
+    return RWR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rwr_dist_gather_rgba8(rwr_context *ctx, int root)
+{
+    int rc = gather_checks(ctx, root, true);
+    if (rc != RWR_OK) return rc;
     DeviceGuard g(ctx->device);
     FrameSlot &sl = ctx->slots[ctx->cur];
+    rwr_context::GatherSet &gs = ctx->gather[ctx->cur];
     const hipStream_t stream = sl.stream;   // the frame rendered last: the exchange follows it in stream order
-    const size_t row_bytes = (size_t)ctx->screen.width * 4u;
     const bool is_root = ctx->dist_rank == root;
-    if (is_root) RWR_HIP_CHECK(ctx->d_gathered.ensure(row_bytes * ctx->screen.height));
-    if (ctx->n_slots > 1u) RWR_HIP_CHECK(hipStreamWaitEvent(stream, ctx->gather_done, 0));   // one receive buffer: gathers do not overlap
-    uint32_t r0 = 0, r1 = 0;
-    (void)rwr_dist_band((uint32_t)ctx->dist_rank, (uint32_t)ctx->dist_world, ctx->screen.height, &r0, &r1);
-    RWR_NCCL_CHECK(g_rccl.GroupStart());
-    if (r1 > r0)
-        RWR_NCCL_CHECK(g_rccl.Send(sl.d_color.ptr + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes, ncclUint8, root, ctx->comm, stream));
-    if (is_root)
-        for (int r = 0; r < ctx->dist_world; r++) {   // bands land in final image order
-            uint32_t a = 0, b = 0;
-            (void)rwr_dist_band((uint32_t)r, (uint32_t)ctx->dist_world, ctx->screen.height, &a, &b);
-            if (b > a)
-                RWR_NCCL_CHECK(g_rccl.Recv(ctx->d_gathered.ptr + (size_t)a * row_bytes, (size_t)(b - a) * row_bytes, ncclUint8, r, ctx->comm, stream));
-        }
-    RWR_NCCL_CHECK(g_rccl.GroupEnd());
-    RWR_HIP_CHECK(hipEventRecord(ctx->gather_done, stream));
-    ctx->gathered_valid = is_root;
+    const uint32_t world = (uint32_t)ctx->dist_world;
+    RWR_HIP_CHECK(gather_set_events(ctx, gs));
+    if (is_root) RWR_HIP_CHECK(gs.d_gathered.ensure((size_t)ctx->screen.width * 4u * ctx->screen.height));
+    size_t my_off = 0, my_bytes = 0;
+    band_span(ctx, (uint32_t)ctx->dist_rank, world, &my_off, &my_bytes);
+    if ((rc = order_exchange_begin(ctx, stream)) != RWR_OK) return rc;
+    rc = rccl_gather_exchange(ctx, root, sl.d_color.ptr + my_off, my_bytes,
+                              [&](uint32_t r) { size_t o, b; band_span(ctx, r, world, &o, &b); return gs.d_gathered.ptr + o; },   // bands land in final image order
+                              [&](uint32_t r) { size_t o, b; band_span(ctx, r, world, &o, &b); return b; }, stream);
+    if (rc != RWR_OK) return rc;
+    RWR_HIP_CHECK(hipEventRecord(ctx->exchange_done, stream));
+    RWR_HIP_CHECK(hipEventRecord(gs.done, stream));
+    gs.valid = is_root;
+    ctx->last_gather = ctx->cur;
     return RWR_OK;
 }
 
 // The interleaved partition (rwr_render_strips(ctx, ..., rank, world)): rank r owns strips r, r + world, ...  Every rank packs
-// its strips into one contiguous message (one strided device copy), the root receives the messages side by side and deals
-// the strips out into the frame (one strided device copy per rank): still ONE grouped RCCL exchange per frame.
+// its strips into one contiguous message (one launch), the root receives the messages side by side and deals the strips out
+// into the frame (one launch): still ONE grouped RCCL exchange per frame.  Layout: rwr_strips.h.
 int rwr_dist_gather_strips_rgba8(rwr_context *ctx, int root)
 {
-    if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
-    if (!ctx->comm) return set_error(RWR_ERR_NOT_READY, "rwr_dist_init has not been called");
-    if (root < 0 || root >= ctx->dist_world) return set_error(RWR_ERR_INVALID_ARGUMENT, "root %d outside world %d", root, ctx->dist_world);
-    if (ctx->screen.width == 0) return set_error(RWR_ERR_NOT_READY, "rwr_resize has not been called");
+    int rc = gather_checks(ctx, root, true);
+    if (rc != RWR_OK) return rc;
     DeviceGuard g(ctx->device);
     FrameSlot &sl = ctx->slots[ctx->cur];
+    rwr_context::GatherSet &gs = ctx->gather[ctx->cur];
     const hipStream_t stream = sl.stream;   // the frame rendered last: the exchange follows it in stream order
-    const uint32_t h = ctx->screen.height, world = (uint32_t)ctx->dist_world;
-    const size_t row_bytes = (size_t)ctx->screen.width * 4u, strip_bytes = row_bytes * kStripRows;
-    const uint32_t n_strips = (h + kStripRows - 1u) / kStripRows, tail_rows = h % kStripRows;   // (the frame's last strip may be short)
-    // rank r: its strips, how many of them are whole, its rows
-    auto strips_of = [&](uint32_t r) { return r < n_strips ? (n_strips - r + world - 1u) / world : 0u; };
-    auto owns_tail = [&](uint32_t r) { return tail_rows != 0u && (n_strips - 1u) % world == r; };
-    auto rows_of = [&](uint32_t r) { return strips_of(r) * kStripRows - (owns_tail(r) ? kStripRows - tail_rows : 0u); };
+    const StripLayout L = StripLayout::make(ctx->screen.height, (uint32_t)ctx->dist_world);
     const bool is_root = ctx->dist_rank == root;
     const uint32_t me = (uint32_t)ctx->dist_rank;
-    RWR_HIP_CHECK(ctx->d_strip_pack.ensure((size_t)std::max(1u, rows_of(me)) * row_bytes));
-    if (is_root) {
-        RWR_HIP_CHECK(ctx->d_gathered.ensure(row_bytes * h));
-        RWR_HIP_CHECK(ctx->d_strip_recv.ensure(row_bytes * h));
+    RWR_HIP_CHECK(gather_set_events(ctx, gs));
+    if (is_root && (rc = strips_stage_root_buffers(ctx, gs, L)) != RWR_OK) return rc;
+    if ((rc = strips_stage_pack(ctx, gs, sl, L, me, stream)) != RWR_OK) return rc;
+    if ((rc = order_exchange_begin(ctx, stream)) != RWR_OK) return rc;
+    rc = rccl_gather_exchange(ctx, root, gs.d_pack.ptr, strips_message_bytes(ctx, L, me),
+                              [&](uint32_t r) { return strips_recv_at(ctx, gs, L, r); },
+                              [&](uint32_t r) { return strips_message_bytes(ctx, L, r); }, stream);
+    if (rc != RWR_OK) return rc;
+    RWR_HIP_CHECK(hipEventRecord(ctx->exchange_done, stream));
+    if (is_root && (rc = strips_stage_deal(ctx, gs, L, stream)) != RWR_OK) return rc;
+    RWR_HIP_CHECK(hipEventRecord(gs.done, stream));
+    gs.valid = is_root;
+    ctx->last_gather = ctx->cur;
+    return RWR_OK;
+}
+
+// One-GPU self-test of the stages above for ANY world size: the context plays every rank in turn.  After
+// rwr_render_strips(ctx, ..., rank, world) (or rwr_render_rows of rank's band) _deposit runs that rank's side of the gather
+// on the frame just rendered — the same pack launch, the same message size, the same receive address — with one device
+// copy standing in for the ncclSend / ncclRecv pair; after the last rank _finish runs the root's side (the same deal-out
+// launch).  rwr_dist_frame / rwr_dist_readback then return what a root would hold.  Needs no communicator.
+int rwr_dist_loopback_deposit(rwr_context *ctx, uint32_t rank, uint32_t world, int strips)
+{
+    int rc = gather_checks(ctx, 0, false);
+    if (rc != RWR_OK) return rc;
+    if (world == 0u || rank >= world) return set_error(RWR_ERR_INVALID_ARGUMENT, "rank %u outside world %u", rank, world);
+    DeviceGuard g(ctx->device);
+    FrameSlot &sl = ctx->slots[ctx->cur];
+    rwr_context::GatherSet &gs = ctx->gather[0];   // one "root": every deposit lands in the same set
+    const hipStream_t stream = sl.stream;
+    const bool first = gs.done == nullptr;
+    RWR_HIP_CHECK(gather_set_events(ctx, gs));
+    if (!first) RWR_HIP_CHECK(hipStreamWaitEvent(stream, gs.done, 0));   // deposits share the set's message buffer
+    if (strips) {
+        const StripLayout L = StripLayout::make(ctx->screen.height, world);
+        if ((rc = strips_stage_root_buffers(ctx, gs, L)) != RWR_OK) return rc;
+        if ((rc = strips_stage_pack(ctx, gs, sl, L, rank, stream)) != RWR_OK) return rc;
+        if (strips_message_bytes(ctx, L, rank))
+            RWR_HIP_CHECK(hipMemcpyAsync(strips_recv_at(ctx, gs, L, rank), gs.d_pack.ptr, strips_message_bytes(ctx, L, rank), hipMemcpyDeviceToDevice, stream));
+    } else {
+        RWR_HIP_CHECK(gs.d_gathered.ensure((size_t)ctx->screen.width * 4u * ctx->screen.height));
+        size_t off = 0, bytes = 0;
+        band_span(ctx, rank, world, &off, &bytes);
+        if (bytes) RWR_HIP_CHECK(hipMemcpyAsync(gs.d_gathered.ptr + off, sl.d_color.ptr + off, bytes, hipMemcpyDeviceToDevice, stream));
     }
-    if (ctx->n_slots > 1u) RWR_HIP_CHECK(hipStreamWaitEvent(stream, ctx->gather_done, 0));   // one set of buffers: gathers do not overlap
-    // pack: whole strips by one strided copy, the short last strip (if it is ours) behind them
-    const uint32_t my_whole = strips_of(me) - (owns_tail(me) ? 1u : 0u);
-    if (my_whole)
-        RWR_HIP_CHECK(hipMemcpy2DAsync(ctx->d_strip_pack.ptr, strip_bytes, sl.d_color.ptr + (size_t)me * strip_bytes, (size_t)world * strip_bytes,
-                                       strip_bytes, my_whole, hipMemcpyDeviceToDevice, stream));
-    if (owns_tail(me))
-        RWR_HIP_CHECK(hipMemcpyAsync(ctx->d_strip_pack.ptr + (size_t)my_whole * strip_bytes, sl.d_color.ptr + (size_t)(n_strips - 1u) * strip_bytes,
-                                     (size_t)tail_rows * row_bytes, hipMemcpyDeviceToDevice, stream));
-    RWR_NCCL_CHECK(g_rccl.GroupStart());
-    if (rows_of(me))
-        RWR_NCCL_CHECK(g_rccl.Send(ctx->d_strip_pack.ptr, (size_t)rows_of(me) * row_bytes, ncclUint8, root, ctx->comm, stream));
-    if (is_root) {
-        size_t at = 0;
-        for (uint32_t r = 0; r < world; r++) {
-            if (rows_of(r)) RWR_NCCL_CHECK(g_rccl.Recv(ctx->d_strip_recv.ptr + at, (size_t)rows_of(r) * row_bytes, ncclUint8, (int)r, ctx->comm, stream));
-            at += (size_t)rows_of(r) * row_bytes;
-        }
-    }
-    RWR_NCCL_CHECK(g_rccl.GroupEnd());
-    if (is_root) {   // deal the strips out into the frame
-        size_t at = 0;
-        for (uint32_t r = 0; r < world; r++) {
-            const uint32_t whole = strips_of(r) - (owns_tail(r) ? 1u : 0u);
-            if (whole)
-                RWR_HIP_CHECK(hipMemcpy2DAsync(ctx->d_gathered.ptr + (size_t)r * strip_bytes, (size_t)world * strip_bytes, ctx->d_strip_recv.ptr + at, strip_bytes,
-                                               strip_bytes, whole, hipMemcpyDeviceToDevice, stream));
-            if (owns_tail(r))
-                RWR_HIP_CHECK(hipMemcpyAsync(ctx->d_gathered.ptr + (size_t)(n_strips - 1u) * strip_bytes, ctx->d_strip_recv.ptr + at + (size_t)whole * strip_bytes,
-                                             (size_t)tail_rows * row_bytes, hipMemcpyDeviceToDevice, stream));
-            at += (size_t)rows_of(r) * row_bytes;
-        }
-    }
-    RWR_HIP_CHECK(hipEventRecord(ctx->gather_done, stream));
-    ctx->gathered_valid = is_root;
+    RWR_HIP_CHECK(hipEventRecord(gs.done, stream));
+    gs.valid = false;
+    return RWR_OK;
+}
+
+int rwr_dist_loopback_finish(rwr_context *ctx, uint32_t world, int strips)
+{
+    int rc = gather_checks(ctx, 0, false);
+    if (rc != RWR_OK) return rc;
+    if (world == 0u) return set_error(RWR_ERR_INVALID_ARGUMENT, "world is 0");
+    rwr_context::GatherSet &gs = ctx->gather[0];
+    if (!gs.done || !gs.d_gathered.ptr) return set_error(RWR_ERR_NOT_READY, "nothing has been deposited");
+    DeviceGuard g(ctx->device);
+    const hipStream_t stream = ctx->slots[ctx->cur].stream;
+    RWR_HIP_CHECK(hipStreamWaitEvent(stream, gs.done, 0));
+    if (strips && (rc = strips_stage_deal(ctx, gs, StripLayout::make(ctx->screen.height, world), stream)) != RWR_OK) return rc;
+    RWR_HIP_CHECK(hipEventRecord(gs.done, stream));
+    gs.valid = true;
+    ctx->last_gather = 0;
     return RWR_OK;
 }
 
 int rwr_dist_frame(rwr_context *ctx, void **d_rgba8)
 {
     if (!ctx || !d_rgba8) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!ctx->gathered_valid) return set_error(RWR_ERR_NOT_READY, "no gathered frame on this rank (rwr_dist_gather_rgba8 on the root)");
-    *d_rgba8 = ctx->d_gathered.ptr;
+    rwr_context::GatherSet &gs = ctx->gather[ctx->last_gather];
+    if (!gs.valid) return set_error(RWR_ERR_NOT_READY, "no gathered frame on this rank (rwr_dist_gather_rgba8 on the root)");
+    *d_rgba8 = gs.d_gathered.ptr;
     return RWR_OK;
 }
 
 int rwr_dist_readback(rwr_context *ctx, uint8_t *rgba8)
 {
     if (!ctx || !rgba8) return set_error(RWR_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!ctx->gathered_valid) return set_error(RWR_ERR_NOT_READY, "no gathered frame on this rank (rwr_dist_gather_rgba8 on the root)");
+    rwr_context::GatherSet &gs = ctx->gather[ctx->last_gather];
+    if (!gs.valid) return set_error(RWR_ERR_NOT_READY, "no gathered frame on this rank (rwr_dist_gather_rgba8 on the root)");
     DeviceGuard g(ctx->device);
-    RWR_HIP_CHECK(hipEventSynchronize(ctx->gather_done));
-    RWR_HIP_CHECK(hipMemcpy(rgba8, ctx->d_gathered.ptr, (size_t)ctx->screen.width * ctx->screen.height * 4u, hipMemcpyDeviceToHost));
+    RWR_HIP_CHECK(hipEventSynchronize(gs.done));
+    RWR_HIP_CHECK(hipMemcpy(rgba8, gs.d_gathered.ptr, (size_t)ctx->screen.width * ctx->screen.height * 4u, hipMemcpyDeviceToHost));
     return RWR_OK;
 }
 
@@ -1574,17 +1718,15 @@ int rwr_dist_barrier(rwr_context *ctx)
 int rwr_dist_destroy(rwr_context *ctx)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    DeviceGuard g(ctx->device);
+    (void)sync_all(ctx);
     if (ctx->comm) {
-        DeviceGuard g(ctx->device);
-        (void)sync_all(ctx);
         (void)g_rccl.CommDestroy(ctx->comm);
         ctx->comm = nullptr;
     }
-    if (ctx->gather_done) { (void)hipEventDestroy(ctx->gather_done); ctx->gather_done = nullptr; }
-    ctx->d_gathered.release();
-    ctx->d_strip_pack.release();
-    ctx->d_strip_recv.release();
-    ctx->gathered_valid = false;
+    if (ctx->exchange_done) { (void)hipEventDestroy(ctx->exchange_done); ctx->exchange_done = nullptr; }
+    for (rwr_context::GatherSet &gs : ctx->gather) gs.release();
+    ctx->last_gather = 0;
     ctx->dist_world = 0;
     return RWR_OK;
 }

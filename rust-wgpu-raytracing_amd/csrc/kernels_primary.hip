@@ -360,6 +360,7 @@ hipError_t preload_kernels()
     if (e == hipSuccess) e = preload_kernels_wavefront();
     if (e == hipSuccess) e = preload_kernels_wf_primary();
     if (e == hipSuccess) e = preload_kernels_wf_bounce();
+    if (e == hipSuccess) e = preload_kernels_dist();
     return e;
 }
 

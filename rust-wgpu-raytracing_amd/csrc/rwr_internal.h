@@ -284,6 +284,15 @@ hipError_t preload_kernels_primary_p2();
 hipError_t preload_kernels_wavefront();
 hipError_t preload_kernels_wf_primary();
 hipError_t preload_kernels_wf_bounce();
+hipError_t preload_kernels_dist();
+
+// kernels_dist.hip: the interleaved partition's gather (layout: rwr_strips.h) — every rank packs its strips into one message,
+// the root deals the received messages out into the frame; one launch each.  The _host forms move host memory the same way.
+struct StripLayout;
+hipError_t launch_strips_pack(hipStream_t s, const StripLayout &L, uint32_t rank, uint32_t row_bytes, const uint8_t *frame, uint8_t *message);
+hipError_t launch_strips_deal(hipStream_t s, const StripLayout &L, uint32_t row_bytes, const uint8_t *recv, uint8_t *frame);
+void strips_pack_host(const StripLayout &L, uint32_t rank, size_t row_bytes, const uint8_t *frame, uint8_t *message);
+void strips_deal_host(const StripLayout &L, size_t row_bytes, const uint8_t *recv, uint8_t *frame);
 
 // kernels_selftest.hip: out[0..3] += depth inputs compared, mismatches, normalize inputs compared, mismatches
 hipError_t launch_selftest_exact_math(hipStream_t s, unsigned long long *d_out4, uint32_t normalize_count, uint32_t seed);
