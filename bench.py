@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mray/s and ms/frame, suzanne_lowpoly at 1920x1080 (BASELINE.json).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks as fresh child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config loop                           (the reference's redraw loop: controller + uniform + render per frame)
 
 A "step" is one frame of the reference's render loop (clear + 2 sphere passes +
 mesh pass, /root/reference/src/lib.rs:1024-1184) through the C ABI of
@@ -50,6 +51,13 @@ CONFIGS = {
     "cfg2b": dict(scene="suzanne_lowpoly.obj", width=1920, height=1080, spp=1, bounces=0,
                   camera=dict(eye=(0, 0, 3), target=(0, 0, -1)),
                   label="suzanne_lowpoly.obj 1920x1080 1spp primary rays, eye (0,0,3) + 2 spheres"),
+    # the reference's redraw loop (State::update + State::render, /root/reference/src/lib.rs:994-1010,1335-1337)
+    # on configs[1]'s scene: every frame CircleCameraController::update_camera (circle_camera_control.rs:76-105) with a scripted
+    # key, CameraInvUniform::update_view_proj (lib.rs:105-111), rwr_render.  The keys S, D, W, A in turn wobble the camera about
+    # the reference pose, so every frame has a new uniform and much the same work as cfg2.
+    "loop": dict(scene="suzanne_lowpoly.obj", width=1920, height=1080, spp=1, bounces=0,
+                 camera=dict(eye=(0, 0, 0), target=(0, 0, -1)), loop_keys="SDWA",
+                 label="suzanne_lowpoly.obj 1920x1080 1spp, moving camera: controller update + inverse uniform + render per frame (SURVEY §8(f)1)"),
     "cfg1": dict(scene="cube.obj", width=256, height=256, spp=1, bounces=0,
                  camera=dict(eye=(0, 0, 0), target=(0, 0, -1)),
                  label="cube.obj 256x256 1spp primary rays (configs[0])"),
@@ -98,6 +106,39 @@ def cpu_baseline(cfg, budget_s: float) -> dict:
     }
 
 
+def spawn_ranks(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (this parent has made no
+    GPU call and imports neither torch nor the library), one per GPU, with the environment torch.distributed.run would give
+    them; forward rank 0's JSON line; fail if any rank fails."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    for ln in (out0 or "").splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return max(c if c > 0 else 1 for c in codes if c)
+    if not lines:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,8 +147,7 @@ def main() -> int:
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--frames-in-flight", type=int, default=None,
-                    help="target sets / streams the context alternates between (default: 2 for the single-GPU "
-                         "frame kernel, 1 with a gather or the wavefront integrator)")
+                    help="frame slots (targets, per-frame records, stream, gather buffers) the context alternates between; default 2")
     ap.add_argument("--skip-serial", action="store_true",
                     help="leave out the one-frame-at-a-time segment after the timed region (profiling runs: every frame of the "
                          "process then runs the same schedule)")
@@ -115,6 +155,8 @@ def main() -> int:
                     help="initialise torch.distributed (RCCL) and run the gather path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])   # before torch or the library are imported: the parent never touches a GPU
     # defaults: 16 us frames need ~1000 of them before the clocks and caches have settled (50: 4 % slower)
     if args.steps is None:
         args.steps = cfg.get("steps", 4000)
@@ -130,9 +172,8 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            return 2
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the render path has no CPU fallback", file=sys.stderr)
         return 2
@@ -176,13 +217,23 @@ def main() -> int:
     # Frames in flight: like a swapchain, the context owns two sets of targets and alternates between
     # them, so one frame's kernel ramps up while the previous frame's last waves drain (at 1080p about
     # 40 % of a lone frame kernel is its first and last waves' latency chain; a slot also owns a set of the
-    # wavefront integrator's accumulators and ray queues, so its frames overlap the same way).  With a gather the root has one
-    # receive buffer: 1.
+    # wavefront integrator's accumulators and ray queues, so its frames overlap the same way; and a set of gather buffers, so
+    # the gather of one frame runs beside the render of the next).
     primary_only = cfg["spp"] == 1 and cfg["bounces"] == 0
-    fif = args.frames_in_flight if args.frames_in_flight else (1 if use_dist else 2)
+    fif = args.frames_in_flight if args.frames_in_flight else 2
     ctx.set_frames_in_flight(fif)
 
-    render = ctx.render_call(cam_inv, params, strips=(rank, world)) if use_dist else ctx.render_call(cam_inv, params, rows=(0, h))
+    loop_keys = [dict(W=rwr.KEY_FORWARD, S=rwr.KEY_BACKWARD, A=rwr.KEY_LEFT, D=rwr.KEY_RIGHT)[k] for k in cfg.get("loop_keys", "")]
+    loop_cam = rwr.make_camera(aspect=w / h, **cfg["camera"]) if loop_keys else None
+    if loop_keys and use_dist:
+        print("bench.py: --config loop is a single-GPU measurement", file=sys.stderr)
+        return 2
+    if loop_keys:
+        render = ctx.loop_call(loop_cam, loop_keys, params)   # controller update + inverse uniform + rwr_render, every frame
+    elif use_dist:
+        render = ctx.render_call(cam_inv, params, strips=(rank, world))
+    else:
+        render = ctx.render_call(cam_inv, params, rows=(0, h))
 
     gather = ctx.dist_gather_call(0, strips=True) if use_dist else None
 
@@ -246,6 +297,29 @@ def main() -> int:
         serial_ms_per_frame = ctx.timer_end() / n_serial
         serial_kernel_us, _ = ctx.kernel_timing_stats()
         ctx.set_kernel_timing(0)
+    loop_stats = None
+    if loop_keys:
+        # the host side of a frame alone (controller update + inverse uniform, no render), and what a frame costs the host
+        # thread when it only enqueues (K frames issued back to back, the device drained before and after)
+        ctx.set_frames_in_flight(fif)
+        host_only = ctx.loop_call(loop_cam.copy(), loop_keys, params, render=False)
+        n_host = 20000
+        t_h = time.perf_counter()
+        for _ in range(n_host):
+            host_only()
+        host_us = (time.perf_counter() - t_h) / n_host * 1e6
+        n_enq = max(100, min(400, args.steps))
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
+        for _ in range(n_enq):
+            step()
+        enqueue_us = (time.perf_counter() - t_h) / n_enq * 1e6
+        torch.cuda.synchronize()
+        loop_stats = {"host_us_per_frame_update_and_uniform": round(host_us, 3), "host_us_per_frame_enqueue_total": round(enqueue_us, 3),
+                      "keys": cfg["loop_keys"], "eye_after": [round(float(v), 4) for v in loop_cam["eye"][0]],
+                      "note": "host_us_per_frame_update_and_uniform = rwr_circle_controller_update + rwr_camera_build_inv_uniform through ctypes, no render; "
+                              "host_us_per_frame_enqueue_total = the host thread's time per frame when it issues frames back to back without waiting "
+                              "(update + uniform + rwr_render's launches); ms_per_step is the device-side frame rate with a new uniform every frame"}
     render_only_ms = None
     if use_dist:
         # outside the timed region: the same share WITHOUT the gather, so that the line shows how the frame's time
@@ -289,7 +363,8 @@ def main() -> int:
             kernel = "k_primary_p2"
             note = ("VALU-bound: the scene (face records + 4 MiB linear-float texture) is cache resident and HBM sees only the "
                     "8 B/pixel store (RGBA8 + R32F, each pixel once), so hbm.frac is small by construction (SURVEY §8(d)); "
-                    "frac = VALU issue time of one launch (SQ_ACTIVE_INST_VALU x 4 cycles / SIMDs / measured shader clock) / "
+                    "frac = VALU issue time of one launch (SQ_ACTIVE_INST_VALU x 4 cycles / SIMDs / 2400 MHz spec clock; "
+                    "valu.frac_at_probe_clock uses the shader clock a probe wave measured while the frames rendered) / "
                     "duration_us; duration_us = HIP-event time of the timed region / K launches")
         else:
             # wavefront: SURVEY §8(d) contract figure, 96 B per path segment + 20 B per pixel per frame
@@ -303,27 +378,55 @@ def main() -> int:
                     "primary stage and 3 by the trace kernels in every launch group, all 4 read + cleared by the resolve, 4 B RGBA8 — "
                     "an upper bound: tiles that see nothing are never touched), and traffic is what the counters saw")
         # Counters of the dominant kernel(s) per step from the committed PMC passes (they cannot be collected live
-        # inside this process); valid only for the exact workload they were measured on.
-        counters = None
+        # inside this process); valid only for the exact code, workload and schedule they were measured on — the file
+        # records the hash of the library's sources and the schedule, and the line says when this run is something else.
+        counters, counters_tree, counters_file = None, None, None
+        csrc_tree = rwr.csrc_tree()
+        overrides = sorted(k for k in os.environ if k.startswith("RWR_"))
         if world == 1:
             try:
                 import glob
-                with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")))[-1]) as fh:
-                    counters = json.load(fh).get(args.config)
+                counters_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")))[-1]
+                with open(counters_file) as fh:
+                    doc = json.load(fh)
+                counters = doc.get("cfg2" if args.config == "loop" else args.config)   # (the loop's frames wobble about cfg2's pose)
+                counters_tree = doc.get("_csrc_tree")
             except (OSError, IndexError, ValueError):
                 counters = None
+        stale_why = []
+        if counters:
+            if counters_tree != csrc_tree:
+                stale_why.append(f"library sources changed since the counters were collected ({counters_tree} -> {csrc_tree})")
+            if overrides:
+                stale_why.append("environment overrides " + ",".join(overrides))
+            if counters.get("frames_in_flight", 2) != fif:
+                stale_why.append(f"frames in flight {fif}, counters collected with {counters.get('frames_in_flight', 2)}")
+            if args.config == "loop":
+                stale_why.append("moving camera: counters are cfg2's (fixed reference pose)")
         traffic = counters.get("traffic_bytes_per_step") if counters else None
         n_simd = 4 * info["cu_count"]
         valu = None
+        SPEC_MHZ = 2400.0   # MI355X_MICROARCH.md: peak engine clock
         if counters and counters.get("SQ_ACTIVE_INST_VALU") and clk:
-            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs (MI355X_MICROARCH.md constants table)
-            valu_us = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / n_simd / workload_mhz
-            valu = {"issue_us_per_step": round(valu_us, 3), "SQ_ACTIVE_INST_VALU": counters["SQ_ACTIVE_INST_VALU"],
-                    "SQ_INSTS_VALU": counters.get("SQ_INSTS_VALU"), "simds": n_simd,
-                    "shader_mhz_while_rendering": round(workload_mhz, 1), "shader_mhz_under_fma_load": round(clk["shader_mhz"], 1),
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs (MI355X_MICROARCH.md constants table).  Issue TIME needs
+            # a clock: the chip's specified 2.4 GHz gives the fraction reported as roofline.frac (reproducible from profiles/ and
+            # this line alone); the clock a probe wave measured while these frames rendered gives frac_at_probe_clock beside it.
+            cycles_per_simd = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / n_simd
+            valu_us_spec = cycles_per_simd / SPEC_MHZ
+            probe_ok = bool(workload_mhz and workload_mhz > 0.0)
+            valu_us_probe = cycles_per_simd / workload_mhz if probe_ok else None
+            valu = {"issue_us_per_step": round(valu_us_spec, 3), "issue_us_per_step_at_probe_clock": round(valu_us_probe, 3) if probe_ok else None,
+                    "SQ_ACTIVE_INST_VALU": counters["SQ_ACTIVE_INST_VALU"],
+                    "SQ_INSTS_VALU": counters.get("SQ_INSTS_VALU"), "simds": n_simd, "cycles_per_simd": round(cycles_per_simd, 1),
+                    "spec_mhz": SPEC_MHZ, "shader_mhz_while_rendering": round(workload_mhz, 1) if probe_ok else None,
+                    "shader_mhz_under_fma_load": round(clk["shader_mhz"], 1),
                     "cycles_per_wave64_v_fma_f32": round(clk["cycles_per_v_fma_f32"], 3),
                     "cycles_per_wave64_v_pk_fma_f32": round(clk["cycles_per_v_pk_fma_f32"], 3),
-                    "frac": round(valu_us * 1e-6 / launch_s, 4), "counters_from": counters.get("source")}
+                    "frac": round(valu_us_spec * 1e-6 / launch_s, 4), "frac_at_2400mhz": round(valu_us_spec * 1e-6 / launch_s, 4),
+                    "frac_at_probe_clock": round(valu_us_probe * 1e-6 / launch_s, 4) if probe_ok else None,
+                    "counters_from": counters.get("source"), "kernel": counters.get("dominant_kernel")}
+            if counters.get("dominant_kernel") and primary_only_cfg:
+                kernel = counters["dominant_kernel"]
         hbm_achieved = algo_bytes / launch_s / 1e9
         hbm = {"achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 5),
                "algorithmic_bytes_per_step": algo_bytes}
@@ -342,6 +445,8 @@ def main() -> int:
             "valu": valu, "hbm": hbm, "valu_frac": valu["frac"] if valu else None, "hbm_frac": hbm["frac"],
             "duration_us": round(launch_s * 1e6, 3), "launch_us_pipelined": round(kernel_us, 3) if kernel_samples else None,
             "launch_us_pipelined_samples": kernel_samples, "timed_region_instrumented": False, "note": note,
+            "csrc_tree": csrc_tree, "counters_tree": counters_tree, "counters_file": os.path.relpath(counters_file, ROOT) if counters_file else None,
+            "counters_stale": bool(stale_why) if counters else None, "counters_stale_why": stale_why or None,
         })
         if serial_kernel_us:
             roofline["launch_us_serial"] = round(serial_kernel_us, 3)
@@ -360,6 +465,8 @@ def main() -> int:
             out["ms_per_frame_render_only"] = round(render_only_ms, 5)   # slowest rank's share, no gather (not timed above)
         if gathered_ok is not None:
             out["config"]["gathered_frame_ok"] = gathered_ok
+        if loop_stats is not None:
+            out["loop"] = loop_stats
     if use_dist:
         ctx.dist_destroy()
     ctx.close()

@@ -441,6 +441,27 @@ class Context:
 
         return call
 
+    def loop_call(self, cam: np.ndarray, keys: list[int], params, speed: float = CONTROLLER_SPEED, render: bool = True):
+        """One iteration of the reference's redraw loop (State::update + State::render, src/lib.rs:994-1010,1335-1337) per call:
+        CircleCameraController::update_camera with the next key mask of `keys` (cycled), CameraInvUniform::update_view_proj,
+        rwr_render.  Arguments are marshalled once; `cam` is advanced in place.  render=False: the host side alone."""
+        L, h = lib(), self._h
+        upd, inv, ren = L.rwr_circle_controller_update, L.rwr_camera_build_inv_uniform, L.rwr_render
+        uni = np.zeros(1, dtype=CAMERA_INV_DTYPE)
+        pc, pu, pp = _p(cam), _p(uni), _p(params)
+        sp = C.c_float(speed)
+        masks = [C.c_uint32(k) for k in keys]
+        state = [0]
+
+        def call(_keep=(cam, uni, params)):
+            i = state[0]
+            state[0] = i + 1 if i + 1 < len(masks) else 0
+            rc = upd(sp, masks[i], pc) or inv(pc, pu) or (ren(h, pu, pp) if render else 0)
+            if rc:
+                _check(rc)
+
+        return call
+
     def synchronize(self):
         _check(lib().rwr_synchronize(self._h))
 
@@ -549,6 +570,24 @@ class Context:
         a, b = C.c_uint64(), C.c_uint64()
         _check(lib().rwr_last_render_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+
+def csrc_tree() -> str:
+    """Hash of the sources librwr_hip.so is built from (csrc/, host/, include/rwr_hip.h, Makefile): ties a set of profiler
+    counters (profiles/r*_counters.json `_csrc_tree`) to the code they were measured on, with or without a .git directory."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = []
+    for sub in ("csrc", "host"):
+        d = os.path.join(_HERE, sub)
+        files += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".hpp", ".hip", ".cpp"))]
+    files += [os.path.join(_HERE, "Makefile"), HEADER_PATH]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, _HERE).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def exported_symbols_declared_in_header() -> list[str]:
