@@ -118,7 +118,13 @@ typedef struct rwr_camera {
     float zfar;
 } rwr_camera;
 
-/* Extension (no reference counterpart): how many samples / bounces to trace. */
+/* Extension (no reference counterpart): how many samples / bounces to trace.
+ * With spp > 1 or max_bounces > 0 a pixel is (sum over samples of E(h0) + albedo(h0) * E(h1)) / spp, E being the reference's
+ * local shading.  Part of that definition: every term a sample adds is clamped per channel — E(h0) to
+ * [0, 16], albedo * E(h1) to [0, 64], NaN counting as 0 — so that the sums have a fixed range (they are added as fixed
+ * point, in any order, and the frame is bit-reproducible).  The reference's materials (components <= 1) come nowhere near;
+ * a material with Ka = 20 is clamped, in the oracle's or_render_path as here.  spp 1 / max_bounces 0 is the reference frame:
+ * nothing is clamped before the rgba8unorm store. */
 typedef struct rwr_render_params {
     uint32_t spp;          /* >= 1.  1 = the reference's single centre sample        */
     uint32_t max_bounces;  /* 0 = reference (primary rays only); 1 = one diffuse bounce */

@@ -811,6 +811,11 @@ static inline v3 shade_any(const Scene *sc, int32_t id, const HitRecord *h, Ray 
     return shade_sphere(h, ray, albedo);
 }
 
+/* Range of one sample's terms (extension; include/rwr_hip.h rwr_render_params): see render_path_core. */
+#define OR_PATH_E0_CAP 16.0f
+#define OR_PATH_E1_CAP 64.0f
+static inline float term_clamp(float x, float cap) { return x > 0.0f ? (x < cap ? x : cap) : 0.0f; }
+
 /* Multi-material form: face i (before instancing) uses materials[face_material[i]] and the
  * texture (tex_ptrs[k], tex_ws[k], tex_hs[k]) of that material; face_material == NULL means
  * "everything uses material 0".  Faces of all parts are one flat list (part order, then face
@@ -918,7 +923,15 @@ static int render_path_core(const OrCameraInvUniform *cam, const OrScreen *scree
                 if (id == -1) continue;
                 v3 albedo;
                 v3 e0 = shade_any(&sc, id, &win, ray, &albedo);
-                acc[0] += e0.x; acc[1] += e0.y; acc[2] += e0.z; acc[3] += 2.0f;
+                /* the extension's definition: every term a sample adds to a pixel is clamped per channel — E(h0) to
+                 * [0, 16], albedo * E(h1) to [0, 64] (NaN counts as 0) — so that sums of terms have a fixed range (the HIP
+                 * integrator adds them as fixed point).  Materials with components <= 1 never come near either. */
+                if (spp != 1 || bounce) {   /* (spp 1, no bounce IS the reference frame: nothing is clamped before the store) */
+                    acc[0] += term_clamp(e0.x, OR_PATH_E0_CAP); acc[1] += term_clamp(e0.y, OR_PATH_E0_CAP); acc[2] += term_clamp(e0.z, OR_PATH_E0_CAP);
+                } else {
+                    acc[0] += e0.x; acc[1] += e0.y; acc[2] += e0.z;
+                }
+                acc[3] += 2.0f;
                 if (bounce) {
                     v3 P = madd3(win.distance, ray.direction, ray.origin);
                     Ray br;
@@ -928,7 +941,8 @@ static int render_path_core(const OrCameraInvUniform *cam, const OrScreen *scree
                     int32_t id1 = scene_nearest(&sc, br, &h1);
                     if (id1 != -1) {
                         v3 e1 = shade_any(&sc, id1, &h1, br, NULL);
-                        acc[0] += albedo.x * e1.x; acc[1] += albedo.y * e1.y; acc[2] += albedo.z * e1.z;
+                        acc[0] += term_clamp(albedo.x * e1.x, OR_PATH_E1_CAP); acc[1] += term_clamp(albedo.y * e1.y, OR_PATH_E1_CAP);
+                        acc[2] += term_clamp(albedo.z * e1.z, OR_PATH_E1_CAP);
                     }
                 }
             }

@@ -175,8 +175,9 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
     const float rw = refined_rcp(fw), rh = refined_rcp(fh);
     const f3 O = ld3(p.cam.origin);
 
-    // the group's sums of E(h0) per pixel as 2^-22 fixed point in 32 bits (a sample's term is capped at 1024 / kWfMaxGroup, so
-    // a whole group fits; shifted into the planes' 2^-26 units at the end: WfBuffers::fix), and its primary hits
+    // the group's sums of E(h0) per pixel as 2^-22 fixed point in 32 bits (a sample's term is clamped to kWfE0Cap = 16 — part of
+    // the integrator's definition, rwr_hip.h / oracle render_path_core — so a whole group of <= 64 fits; shifted into the planes'
+    // 2^-26 units at the end: WfBuffers::fix), and its primary hits
     uint32_t fr0 = 0, fg0 = 0, fb0 = 0, fr1 = 0, fg1 = 0, fb1 = 0;
     uint32_t hits0 = 0, hits1 = 0;
     uint32_t emitted = 0;  // rays this wave emitted in this launch (wave-uniform)
@@ -315,7 +316,8 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
         {   // (cr, cg, cb are 0 where nothing was hit; float -> u32 conversion sends NaN / negatives to 0; alpha is 1 + 1 on a
             // written pixel, :231-234)
             constexpr float kScale22 = kWfFixedScale / 16.0f;
-            constexpr uint32_t kCap = ((1024u / kWfMaxGroup) << 22) - 1u;   // (kWfMaxGroup samples of it fit 32 bits)
+            constexpr uint32_t kCap = (kWfE0Cap << 22) - 1u;
+            static_assert((unsigned long long)kWfMaxGroup * (kWfE0Cap << 22) <= (1ull << 32), "a launch group's sum of clamped terms fits 32 bits");
             const f2 sr = cr * kScale22, sg = cg * kScale22, sb = cb * kScale22;
             fr0 += min((uint32_t)sr.x, kCap); fg0 += min((uint32_t)sg.x, kCap); fb0 += min((uint32_t)sb.x, kCap);
             fr1 += min((uint32_t)sr.y, kCap); fg1 += min((uint32_t)sg.y, kCap); fb1 += min((uint32_t)sb.y, kCap);

@@ -205,8 +205,12 @@ constexpr uint32_t kWfTileW = 64, kWfTileH = 8, kWfTilePixels = kWfTileW * kWfTi
 #define RWR_WF_MAX_GROUP 64
 #endif
 constexpr uint32_t kWfMaxGroup = RWR_WF_MAX_GROUP;   // samples per launch group at most (the sort's LDS: 4 B per ray of a pool = 128 KiB at 64;
-                                                     // the primary stage's 32-bit sums: a sample's term saturates at 2^10 / kWfMaxGroup)
+                                                     // the primary stage's 32-bit sums: kWfMaxGroup terms of at most kWfE0Cap)
 constexpr float kWfFixedScale = 67108864.0f;  // 2^26: a term < 64, thousands of them < 2^64
+// The integrator's definition (rwr_hip.h rwr_render_params; oracle render_path_core): a sample's E(h0) is clamped to [0, 16] per
+// channel, its albedo * E(h1) to [0, 64] (= what a u32 of 2^-26 units holds: the float -> u32 conversion saturates).  Fixed
+// numbers, not tuning parameters.
+constexpr uint32_t kWfE0Cap = 16;
 #ifndef RWR_WF_CELL_BITS
 #define RWR_WF_CELL_BITS 4
 #endif

@@ -255,3 +255,30 @@ def test_launch_groups_of_64_samples(rwr, orc, suzanne):
         _check(frames[-1], want, spp)
     for k in ("color", "color_f32", "depth", "obj_id", "hit_t"):
         assert np.array_equal(frames[0][k].view(np.uint8), frames[1][k].view(np.uint8)), k
+
+
+def test_terms_beyond_the_clamp(rwr, orc, gpu_ctx, suzanne):
+    """The integrator's definition clamps a sample's E(h0) at 16 and its albedo * E(h1) at 64 per channel (rwr_hip.h
+    rwr_render_params; oracle render_path_core): the HIP pipeline adds terms as fixed point and needs a range.  A material with
+    Ka = (20, 3, 0.5): red is clamped, green and blue are not — oracle and GPU agree within the colour bar on float colour
+    (not only after the rgba8 store), and the clamp shows (red's sample mean stays at 16, far below Ka's 20)."""
+    w, h = 96, 54
+    model = dict(suzanne)
+    model["material"] = suzanne["material"].copy()
+    model["material"]["ambient"][0] = (20.0, 3.0, 0.5)
+    cam_inv = rwr.camera_build_inv_uniform(rwr.make_camera(eye=(0, 0, 3), target=(0.2, 0.2, -2.0), aspect=w / h))
+    for spp, bounces in ((3, 0), (4, 1)):
+        params = rwr.make_params(spp=spp, max_bounces=bounces, seed=5, flags=rwr.FLAG_AUX_OUTPUTS)
+        got = _gpu(rwr, gpu_ctx, model, rwr.make_spheres(), cam_inv, w, h, params)
+        want = orc.render_path(cam_inv.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h),
+                               orc.make_params(spp, bounces, seed=5), orc.make_spheres(), model)
+        assert np.array_equal(got["obj_id"], want["obj_id"])
+        err = np.abs(got["color_f32"] - want["color_f32"]).max()
+        assert err <= 2e-4, err        # (terms of up to 64: the unorm16 throughput moves a bounce term by up to 64 x 8e-6)
+        assert np.array_equal(got["color"], want["color"]) or np.abs(got["color"].astype(int) - want["color"].astype(int)).max() <= 1
+        inside = (want["obj_id"] >= 0) & (want["color_f32"][..., 3] == 2.0)      # pixels every sample of which hit the mesh
+        assert inside.sum() > 50
+        red = want["color_f32"][..., 0][inside]
+        if bounces == 0:
+            assert np.all(red == 16.0)                                           # E(h0).r >= Ka.r = 20 everywhere: clamped
+        assert np.all(got["color_f32"][..., 1][inside] >= 3.0 - 1e-3)            # green: Ka.g = 3 is not clamped
