@@ -53,10 +53,10 @@ CONFIGS = {
                   label="suzanne_lowpoly.obj 1920x1080 1spp primary rays, eye (0,0,3) + 2 spheres"),
     # the reference's redraw loop (State::update + State::render, /root/reference/src/lib.rs:994-1010,1335-1337)
     # on configs[1]'s scene: every frame CircleCameraController::update_camera (circle_camera_control.rs:76-105) with a scripted
-    # key, CameraInvUniform::update_view_proj (lib.rs:105-111), rwr_render.  The keys S, D, W, A in turn wobble the camera about
+    # key, CameraInvUniform::update_view_proj (lib.rs:105-111), rwr_render.  The keys S, W, D, A in turn (exactly periodic) wobble the camera about
     # the reference pose, so every frame has a new uniform and much the same work as cfg2.
     "loop": dict(scene="suzanne_lowpoly.obj", width=1920, height=1080, spp=1, bounces=0,
-                 camera=dict(eye=(0, 0, 0), target=(0, 0, -1)), loop_keys="SDWA",
+                 camera=dict(eye=(0, 0, 0), target=(0, 0, -1)), loop_keys="SWDA",
                  label="suzanne_lowpoly.obj 1920x1080 1spp, moving camera: controller update + inverse uniform + render per frame (SURVEY §8(f)1)"),
     "cfg1": dict(scene="cube.obj", width=256, height=256, spp=1, bounces=0,
                  camera=dict(eye=(0, 0, 0), target=(0, 0, -1)),

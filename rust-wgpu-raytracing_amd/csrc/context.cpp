@@ -1006,6 +1006,19 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
         const bool overlap = n_queues > 1u;
         const size_t slots = (size_t)n_tiles * group * kWfTilePixels;
         if (rp.max_bounces) {
+            // The ray queues are fixed-slot (space instead of atomics: 36 B per slot of every tile of the launch), the one large
+            // allocation of the library — 19 GB for a 4K frame at 64 samples per group.  A frame whose queues cannot be held is
+            // refused with its size, not left to a failed hipMalloc half-way through.
+            if (W.d_rays.count < n_queues * 2u * slots) {
+                const size_t need = n_queues * slots * (2u * sizeof(float4) + 2u * sizeof(uint16_t));
+                const size_t held = W.d_rays.count * sizeof(float4) + (W.d_sorted.count + W.d_bins.count) * sizeof(uint16_t);
+                size_t free_b = 0, total_b = 0;
+                RWR_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+                if (need > free_b + held)
+                    return set_error(RWR_ERR_UNSUPPORTED, "the frame's ray queues need %.1f GB (%zu tiles x %u samples per launch group x 512 slots x 36 B x %zu queues), "
+                                     "%.1f GB are free: fewer frames in flight (each slot holds its own queues) or RWR_WF_GROUP < %u",
+                                     need * 1e-9, (size_t)n_tiles, group, n_queues, (free_b + held) * 1e-9, group);
+            }
             RWR_HIP_CHECK(W.d_rays.ensure(n_queues * 2u * slots));
             RWR_HIP_CHECK(W.d_sorted.ensure(n_queues * slots));
             RWR_HIP_CHECK(W.d_bins.ensure(n_queues * slots));

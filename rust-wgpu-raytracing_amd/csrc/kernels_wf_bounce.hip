@@ -31,6 +31,7 @@
 // Nothing here decides what the first hit shows; bounce rays are the oracle's rays bit for bit (first stage) and
 // their nearest hits are exact, so the stage's output differs from the oracle's only by the fixed-point rounding
 // of the terms and of the throughput (tolerance 1e-4).
+#include <atomic>
 #include <algorithm>
 #include <type_traits>
 
@@ -705,12 +706,18 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
     const bool packets = bvh.stack_depth <= 64u && packet_min_rays <= sample_count * kWfTilePixels && bvh.packet_extent > 0.0f;
     const size_t sort_lds = 2u * (size_t)sample_count * kWfTilePixels * sizeof(uint16_t);
     if (sort_lds > 64u * 1024u) {   // beyond the default limit of dynamic LDS (groups of more than 32 samples)
-        static const hipError_t raised = [] {
-            const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-            const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-            return a != hipSuccess ? a : b;
-        }();
-        if (raised != hipSuccess) return raised;
+        // a function attribute belongs to the function ON ONE DEVICE: raised once per device a context renders on
+        static std::atomic<uint64_t> raised_on{0};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(raised_on.load(std::memory_order_acquire) & bit)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            if (e != hipSuccess) return e;
+            raised_on.fetch_or(bit, std::memory_order_release);
+        }
     }
     if (wf.live_list)
         hipLaunchKernelGGL(k_wf_sort<true>, dim3(std::min(n_tiles, 2048u)), dim3(kWfSortThreads), sort_lds, s, wf, info, counters, pool_list, n_tiles,
