@@ -87,8 +87,14 @@ struct FrameSlot {
     DeviceBuffer<uint32_t> d_bin_lists, d_bin_counts, d_bin_offsets, d_bin_total;   // per-frame screen bins (large scenes)
     uint32_t *h_bin_total = nullptr;   // pinned: entries the last binned frame of this slot needed (read a frame late, never waited for)
     bool aux_valid = false;
+    // RWR_FRAME_GRAPH (A/B knob): the reference frame's two launches (k_frame_setup -> k_primary_p2) as a
+    // hipGraph of this slot — replayed as it is while camera and parameters stay the same, updated in place when they change
+    hipGraphExec_t frame_graph = nullptr;
+    std::vector<unsigned char> frame_graph_key;
     void release_buffers()
     {
+        if (frame_graph) { (void)hipGraphExecDestroy(frame_graph); frame_graph = nullptr; }
+        frame_graph_key.clear();
         d_color.release(); d_depth.release(); d_color_f32.release(); d_obj_id.release(); d_hit_t.release();
         d_ftris.release(); d_tnum.release(); d_ray_colp.release(); d_ray_row.release();
         d_bin_lists.release(); d_bin_counts.release(); d_bin_offsets.release(); d_bin_total.release();
@@ -118,6 +124,7 @@ struct rwr_context {
     uint32_t bin_min_faces = 256;                       // tunable: RWR_BIN_MIN_FACES
     uint32_t bin_min_capacity = 65536;                  // tunable: RWR_BIN_CAPACITY (entries the bin lists start with)
     bool force_one_pixel = false;                       // debug: RWR_ONE_PIXEL_PER_LANE=1
+    uint32_t frame_graph_mode = 0;                      // A/B: RWR_FRAME_GRAPH=1 (hipGraph replay / update of the reference frame's launches)
     // BVH over the (flattened) world-space faces, for bounce rays
     DeviceBuffer<BvhNode4> d_bvh_nodes;
     DeviceBuffer<uint32_t> d_bvh_leaf_faces;
@@ -525,6 +532,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     (void)preload_kernels();   // have the code objects on the device before the first frame asks for them
     if (const char *e2 = std::getenv("RWR_WAVE_CULL_MIN")) ctx->wave_cull_min = (uint32_t)std::strtoul(e2, nullptr, 10);
     if (const char *e4 = std::getenv("RWR_ONE_PIXEL_PER_LANE")) ctx->force_one_pixel = std::atoi(e4) != 0;
+    if (const char *e14 = std::getenv("RWR_FRAME_GRAPH")) ctx->frame_graph_mode = (uint32_t)std::atoi(e14);
     if (const char *e5 = std::getenv("RWR_AUTO_BVH_FACE_PX")) ctx->auto_bvh_face_px = (float)std::atof(e5);
     if (const char *e6 = std::getenv("RWR_WF_GROUP")) ctx->wf_group = std::min(kWfMaxGroup, std::max(1u, (uint32_t)std::strtoul(e6, nullptr, 10)));
     if (const char *e9 = std::getenv("RWR_WF_STATS")) {
@@ -905,23 +913,59 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
     fp.spp = rp.spp;
     fp.seed = rp.seed;
     fp.bounces = rp.max_bounces;
-    {
-        // Per-frame records and tables (k_frame_setup): they depend on the camera, so they are rebuilt
-        // every frame, on the render stream just ahead of the render kernel.  (Running this small
-        // kernel on a side stream, double-buffered so that it overlaps the previous frame, was
-        // measured 4-10 us SLOWER per frame than the 3 us it hides: cross-stream event waits cost
-        // more than the kernel.)
-        FrameSetupOut so{};
-        so.ray_pairs = ((ctx->screen.width + 63u) / 64u) * 32u;  // whole 64-pixel workgroup columns
-        so.ray_rows = ctx->screen.height + 8u;                   // whole 8-row tiles below any band
-        RWR_HIP_CHECK(sl.d_ray_colp.ensure(2u * (size_t)so.ray_pairs));
-        RWR_HIP_CHECK(sl.d_ray_row.ensure(so.ray_rows));
-        so.ftris = sl.d_ftris.ptr; so.tnum = sl.d_tnum.ptr;
-        so.ray_colp = sl.d_ray_colp.ptr; so.ray_row = sl.d_ray_row.ptr;
-        RWR_HIP_CHECK(launch_frame_setup(stream, cc, *camera, ctx->screen.width, ctx->screen.height, ctx->d_cull.ptr,
-                                         ctx->d_tris.ptr, ctx->n_tris, so));
-        fp.ray_colp = so.ray_colp; fp.ray_row = so.ray_row; fp.tnum = so.tnum;
+    // Per-frame records and tables (k_frame_setup): they depend on the camera, so they are rebuilt
+    // every frame, on the render stream just ahead of the render kernel.  (Running this small
+    // kernel on a side stream, double-buffered so that it overlaps the previous frame, was
+    // measured 4-10 us SLOWER per frame than the 3 us it hides: cross-stream event waits cost
+    // more than the kernel.)
+    FrameSetupOut so{};
+    so.ray_pairs = ((ctx->screen.width + 63u) / 64u) * 32u;  // whole 64-pixel workgroup columns
+    so.ray_rows = ctx->screen.height + 8u;                   // whole 8-row tiles below any band
+    RWR_HIP_CHECK(sl.d_ray_colp.ensure(2u * (size_t)so.ray_pairs));
+    RWR_HIP_CHECK(sl.d_ray_row.ensure(so.ray_rows));
+    so.ftris = sl.d_ftris.ptr; so.tnum = sl.d_tnum.ptr;
+    so.ray_colp = sl.d_ray_colp.ptr; so.ray_row = sl.d_ray_row.ptr;
+    fp.ray_colp = so.ray_colp; fp.ray_row = so.ray_row; fp.tnum = so.tnum;
+    // A/B (RWR_FRAME_GRAPH=1): the plain reference frame — records + frame kernel, nothing else on the stream — as one graph launch
+    const bool as_graph = ctx->frame_graph_mode != 0u && !(rp.spp != 1 || rp.max_bounces != 0) && !aux && ctx->n_triangles == 0 &&
+                          !(rp.flags & (RWR_FLAG_ORTHO_RAYS | RWR_FLAG_USE_BVH | RWR_FLAG_NO_CULL | RWR_FLAG_ONE_PIXEL_PER_LANE)) &&
+                          !ctx->force_one_pixel && ctx->n_tris != 0 && ctx->n_tris <= ctx->bin_min_faces && !ctx->timing_every;
+    if (as_graph) {
+        std::vector<unsigned char> key(sizeof(FrameParams) + sizeof(CullConsts));
+        std::memcpy(key.data(), &fp, sizeof fp);
+        std::memcpy(key.data() + sizeof fp, &cc, sizeof cc);
+        if (!sl.frame_graph || key != sl.frame_graph_key) {
+            hipGraph_t g = nullptr;
+            RWR_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            hipError_t e = launch_frame_setup(stream, cc, *camera, ctx->screen.width, ctx->screen.height, ctx->d_cull.ptr, ctx->d_tris.ptr, ctx->n_tris, so);
+            if (e == hipSuccess) e = launch_primary_p2(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0, tg);
+            const hipError_t e2 = hipStreamEndCapture(stream, &g);
+            RWR_HIP_CHECK(e);
+            RWR_HIP_CHECK(e2);
+            bool updated = false;
+            if (sl.frame_graph) {
+                hipGraphNode_t bad = nullptr;
+                hipGraphExecUpdateResult res;
+                updated = hipGraphExecUpdate(sl.frame_graph, g, &bad, &res) == hipSuccess;
+                if (!updated) { (void)hipGetLastError(); (void)hipGraphExecDestroy(sl.frame_graph); sl.frame_graph = nullptr; }
+            }
+            if (!updated) {
+                const hipError_t e3 = hipGraphInstantiate(&sl.frame_graph, g, nullptr, nullptr, 0);
+                if (e3 != hipSuccess) { (void)hipGraphDestroy(g); RWR_HIP_CHECK(e3); }
+            }
+            (void)hipGraphDestroy(g);
+            sl.frame_graph_key.swap(key);
+        }
+        RWR_HIP_CHECK(hipGraphLaunch(sl.frame_graph, stream));
+        ctx->last_spp = 0;
+        ctx->last_had_bounce = false;
+        ctx->last_primary = 0;
+        for (uint32_t y0 = row_begin; y0 < row_end; y0 += row_pitch) ctx->last_primary += (uint64_t)std::min(kStripRows, row_end - y0) * ctx->screen.width;
+        ctx->last_bounce = 0;
+        return RWR_OK;
     }
+    RWR_HIP_CHECK(launch_frame_setup(stream, cc, *camera, ctx->screen.width, ctx->screen.height, ctx->d_cull.ptr,
+                                     ctx->d_tris.ptr, ctx->n_tris, so));
     if (ctx->n_tris && !(rp.flags & RWR_FLAG_NO_CULL)) {
         const uint32_t bins_x = (ctx->screen.width + kBinW - 1) / kBinW, bins_y = (row_end - row_begin + kBinH - 1) / kBinH;
         if (ctx->n_tris > ctx->bin_min_faces) {

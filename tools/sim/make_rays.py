@@ -74,6 +74,7 @@ rays = allr[0]
 np.save(out + "_rays.npy", rays)
 np.save(out + "_hit.npy", hit)
 tri32.tofile(out + "_tris.bin")
+obj.astype(np.int32).tofile(out + "_obj.bin")   # the face every pixel's bounce ray starts on (policy F of the simulator)
 # raw dump for the C++ side: int32 rows, w, then hit mask (u8), rays (f32)
 with open(out + "_rays.bin", "wb") as fh:
     np.array([rays.shape[0], rays.shape[1], tri32.shape[0], S], np.int32).tofile(fh)

@@ -344,5 +344,55 @@ int main(int argc, char **argv)
                    S, nb * nb, (double)c / nr, (double)pk_n / pk_w, (double)pk_f / pk_w, (double)pk_cost / nr);
         }
     }
+    // policy F: pool = all rays of the band that START ON THE SAME FACE (whatever tile their pixel is in), sorted by direction bin
+    if (S > 1) {
+        std::vector<int32_t> objv((size_t)rows * w, -1);
+        if (FILE *fo = fopen((pre + "_obj.bin").c_str(), "rb")) {
+            if (fread(objv.data(), 4, objv.size(), fo) != objv.size()) fprintf(stderr, "short obj file\n");
+            fclose(fo);
+            const int group = argc > 6 ? atoi(argv[6]) : 1;   // faces per pool (consecutive face indices: same instance, roughly neighbours)
+            for (int nb : {4, 8, 16}) {
+                struct E { int bin; RayTrace r; };
+                std::vector<std::vector<E>> pools((ntri + group - 1) / group);
+                for (int sidx = 0; sidx < S; sidx++)
+                    for (size_t i = 0; i < (size_t)rows * w; i++) {
+                        if (!hit[i] || objv[i] < 0) continue;
+                        const float *R = &rays[((size_t)sidx * rows * w + i) * 6];
+                        const float *D = R + 3;
+                        const float l1 = std::fabs(D[0]) + std::fabs(D[1]) + std::fabs(D[2]);
+                        float u = D[0] / l1, v = D[1] / l1;
+                        if (D[2] < 0) { const float uu = (1 - std::fabs(v)) * (u >= 0 ? 1 : -1), vv = (1 - std::fabs(u)) * (v >= 0 ? 1 : -1); u = uu; v = vv; }
+                        const int iu = std::min(nb - 1, (int)((u * 0.5f + 0.5f) * nb)), iv = std::min(nb - 1, (int)((v * 0.5f + 0.5f) * nb));
+                        pools[objv[i] / group].push_back({iv * nb + iu, trace(bvh, R, D)});
+                    }
+                long c = 0, pk_cost = 0, pk_n = 0, pk_f = 0, pk_w = 0; size_t nr = 0, npools = 0;
+                for (auto &pool : pools) {
+                    if (pool.empty()) continue;
+                    npools++;
+                    std::stable_sort(pool.begin(), pool.end(), [](const E &a, const E &b) { return a.bin < b.bin; });
+                    nr += pool.size();
+                    for (size_t base = 0; base < pool.size(); base += 128) {
+                        std::vector<uint8_t> seen_n(bvh.nodes.size(), 0), seen_f(bvh.leaf_faces.size() + 8, 0);
+                        for (size_t e = base; e < std::min(pool.size(), base + 128); e++)
+                            for (auto &st : pool[e].r.steps) {
+                                if (st.kind == 0) seen_n[st.id] = 1;
+                                else for (int k = 0; k < st.nf; k++) seen_f[st.id + k] = std::max<uint8_t>(seen_f[st.id + k], st.stages[k]);
+                            }
+                        long un = 0, uf = 0;
+                        for (auto v : seen_n) un += v;
+                        for (auto v : seen_f) uf += v ? 1 : 0;
+                        pk_cost += un * 130 + uf * 125 + 100; pk_n += un; pk_f += uf; pk_w++;
+                    }
+                    for (size_t base = 0; base < pool.size(); base += 64) {
+                        std::vector<Lane> L(64);
+                        for (int lane = 0; lane < 64 && base + lane < pool.size(); lane++) L[lane].r = &pool[base + lane].r;
+                        c += run_wave_static(L) + 40;
+                    }
+                }
+                printf("pools by origin face (%d faces per pool: %zu pools, %.0f rays each) in %3d direction bins: per-lane %8.1f wave-instr per ray; packets of 128: %.1f nodes + %.1f faces -> %.1f wave-instr per ray\n",
+                       group, npools, (double)nr / npools, nb * nb, (double)c / nr, (double)pk_n / pk_w, (double)pk_f / pk_w, (double)pk_cost / nr);
+            }
+        }
+    }
     return 0;
 }
