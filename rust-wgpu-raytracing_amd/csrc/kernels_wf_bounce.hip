@@ -411,26 +411,6 @@ k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const S
 // persistent loop with global atomics in it, and behind those the compiler would no longer dare to use scalar
 // loads for plain global pointers (it cannot see that nobody writes the scene) — node and face records would come
 // in through the vector memory pipe, 64 identical addresses per load.
-template <typename T> using const_ptr = const __attribute__((address_space(4))) T *;
-template <typename T> RWR_DEV const_ptr<T> to_const_space(const T *p) { return (const_ptr<T>)(p); }
-
-// The fields of a face record the hit test reads, loaded from the constant address space (the loads merge into four
-// s_load_dwordx8 when the index is wave-uniform).
-RWR_DEV TriRecord load_tri_record(const_ptr<TriRecord> rec)
-{
-    const const_ptr<float> f = (const_ptr<float>)rec;
-    TriRecord T;
-    T.p0[0] = f[0]; T.p0[1] = f[1]; T.p0[2] = f[2]; T.d = f[3];
-    T.p1[0] = f[4]; T.p1[1] = f[5]; T.p1[2] = f[6]; T.denom = f[7];
-    T.p2[0] = f[8]; T.p2[1] = f[9]; T.p2[2] = f[10]; T.pad0 = 0.0f;
-    T.N[0] = f[12]; T.N[1] = f[13]; T.N[2] = f[14]; T.pad1 = 0.0f;
-    T.e0[0] = f[16]; T.e0[1] = f[17]; T.e0[2] = f[18]; T.pad2 = 0.0f;
-    T.e1[0] = f[20]; T.e1[1] = f[21]; T.e1[2] = f[22]; T.pad3 = 0.0f;
-    T.e2[0] = f[24]; T.e2[1] = f[25]; T.e2[2] = f[26]; T.pad4 = 0.0f;
-    T.nhat[0] = T.nhat[1] = T.nhat[2] = 0.0f; T.pad5 = 0.0f;
-    return T;
-}
-
 struct PairRays {
     v3 O, D;             // the two rays of a lane
     f2 ix, iy, iz, ox, oy, oz;   // slab constants (rwr_bvh.h make_slab_ray)

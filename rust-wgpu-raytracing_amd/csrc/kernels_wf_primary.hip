@@ -53,16 +53,17 @@ RWR_DEV float refined_rcp(float d)
 }
 
 // pixelToRay (compute.wgsl:150-164) for the pixel-space points (fx.x, fy.x) and (fx.y, fy.y).
-RWR_DEV v3 pixel_pair_ray_dir_at(const rwr_camera_inv_uniform &cam, f2 fx, f2 fy, float width, float height, float rw, float rh)
+template <typename Cam>   // rwr_camera_inv_uniform, possibly in the kernel-argument address space
+RWR_DEV v3 pixel_pair_ray_dir_at(const Cam &cam, f2 fx, f2 fy, float width, float height, float rw, float rh)
 {
     const f2 x_nds = div_shared_rcp(2.0f * fx, splat(width), splat(rw)) - 1.0f;
     const f2 y_nds = div_shared_rcp(2.0f * fy, splat(height), splat(rh)) - 1.0f;
-    const float(&p)[4][4] = cam.proj_inv;
+    const auto &p = cam.proj_inv;
     const f2 vx = p[0][0] * x_nds + p[1][0] * y_nds + p[2][0] * 1.0f + p[3][0] * 1.0f;
     const f2 vy = p[0][1] * x_nds + p[1][1] * y_nds + p[2][1] * 1.0f + p[3][1] * 1.0f;
     const f2 vz = p[0][2] * x_nds + p[1][2] * y_nds + p[2][2] * 1.0f + p[3][2] * 1.0f;
     const f2 vw = splat(0.0f);
-    const float(&m)[4][4] = cam.viewmodel_inv;
+    const auto &m = cam.viewmodel_inv;
     v3 w;
     w.x = m[0][0] * vx + m[1][0] * vy + m[2][0] * vz + m[3][0] * vw;
     w.y = m[0][1] * vx + m[1][1] * vy + m[2][1] * vz + m[3][1] * vw;
@@ -128,42 +129,73 @@ RWR_DEV v3 bounce_direction_pair(v3 n, u2 base, i2 want)
 #ifndef RWR_WF_OCC
 #define RWR_WF_OCC 4
 #endif
-template <bool AUX, bool CULL, bool NMAP, bool LIST = false>
-__global__ void __launch_bounds__(256, (AUX || NMAP) ? 3 : RWR_WF_OCC)
-k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_begin, uint32_t bins_enabled,
-             int32_t mesh_x0, int32_t mesh_y0, int32_t mesh_x1, int32_t mesh_y1, uint32_t sample_begin, uint32_t sample_count,
-             uint32_t z_split, const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
-             const float4 *__restrict__ tex, const Targets tg, const WfBuffers wf)
+// The kernel's ONE argument.  The sample loop is long and uses some 130 wave-uniform words — camera matrices, spheres and their
+// rectangles, a dozen pointers, the face record under test — against 102 scalar registers; the compiler hoists every
+// kernel-argument load out of the loop and then spills (round 2: 86-135 scalar spills through v_writelane / v_readlane, 11-26
+// vector registers in scratch).  So the loop reads what a phase needs through a pointer to the kernel-argument segment that is
+// RE-DERIVED at the phase (wf_args_again: an empty asm the compiler cannot see through), i.e. by scalar loads from the constant
+// cache where the values are used; they are dead again before the next phase.
+struct WfPrimaryArgs {
+    const FrameTri *ftris;
+    uint32_t n_tris, row_begin, bins_enabled;
+    int32_t mesh_x0, mesh_y0, mesh_x1, mesh_y1;
+    uint32_t sample_begin, sample_count, z_split;
+    FrameParams p;
+    const TriRecord *tris;
+    const ShadeRec *shade;
+    const float4 *tex;
+    Targets tg;
+    WfBuffers wf;
+};
+template <typename T> using kernarg = const __attribute__((address_space(4))) T;
+RWR_DEV kernarg<WfPrimaryArgs> *wf_args_again(kernarg<WfPrimaryArgs> *q)
 {
+    asm volatile("" : "+s"(q));
+    return q;
+}
+RWR_DEV f3 ld3(kernarg<float> *q) { return mk3(q[0], q[1], q[2]); }
+
+template <bool AUX, bool CULL, bool NMAP, bool LIST = false>
+// (LIST — frames that show little — keeps an item loop's state on top of everything else and needs 142 registers: three waves
+// per SIMD like the AUX / NMAP forms; such a frame does not fill the chip anyway)
+__global__ void __launch_bounds__(256, (AUX || NMAP || LIST) ? 3 : RWR_WF_OCC)
+k_wf_primary(const WfPrimaryArgs a)
+{
+    kernarg<WfPrimaryArgs> *const ka = (kernarg<WfPrimaryArgs> *)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t sample_begin = a.sample_begin, sample_count = a.sample_count, z_split = a.z_split;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // the bounce stage's counters for this queue start from zero (nothing reads them before this kernel has ended)
-    if (wf.counters && (blockIdx.x | blockIdx.y | blockIdx.z) == 0u && threadIdx.x < 4u) wf.counters[threadIdx.x] = 0u;
+    if (a.wf.counters && (blockIdx.x | blockIdx.y | blockIdx.z) == 0u && threadIdx.x < 4u) a.wf.counters[threadIdx.x] = 0u;
     // which tile, which share of its samples: the launch grid's (x, y, z) — or, on a frame that shows little, item after item
     // of (live tile of k_wf_classify's list) x (share), so that no workgroup is spent on finding its tile empty
     uint32_t bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
     uint32_t item = blockIdx.x, n_items = 0u;
-    if (LIST) n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)*wf.live_count) * z_split;
+    if (LIST) n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)*a.wf.live_count) * z_split;
     do {
+    kernarg<WfPrimaryArgs> *const qi = wf_args_again(ka);   // this tile's set-up: culling inputs, the frame's size and band
+    const uint32_t tiles_x = qi->wf.tiles_x;
     if (LIST) {
         if (item >= n_items) break;
-        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)wf.live_list[item / z_split]);
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)qi->wf.live_list[item / z_split]);
         z = item % z_split;
-        by = t / wf.tiles_x;
-        bx = t - by * wf.tiles_x;
+        by = t / tiles_x;
+        bx = t - by * tiles_x;
         item += gridDim.x;
     }
+    const uint32_t row_begin = qi->row_begin, width = qi->p.width;
     const uint32_t blk_x0 = bx * kWfTileW;
     const uint32_t tile_x0 = blk_x0 + (wave & 1u) * 32u;
-    const uint32_t tile_y0 = row_begin + by * p.row_pitch + (wave >> 1) * 4u;
+    const uint32_t tile_y0 = row_begin + by * qi->p.row_pitch + (wave >> 1) * 4u;
     const uint32_t px0 = tile_x0 + 2u * (lane & 15u), py = tile_y0 + (lane >> 4);
     constexpr float kTileWf = 32.0f, kTileHf = 4.0f;
-    const bool in0 = py < p.row_end && px0 < p.width, in1 = in0 && (px0 + 1u < p.width);
-    const uint32_t pix0 = py * p.width + px0;  // GLOBAL pixel index: RNG key and accumulator slot (< 2^30, rwr_resize)
-    const uint32_t tile = by * wf.tiles_x + bx;
+    const bool in0 = py < qi->p.row_end && px0 < width, in1 = in0 && (px0 + 1u < width);
+    const uint32_t pix0 = py * width + px0;  // GLOBAL pixel index: RNG key and accumulator slot (< 2^30, rwr_resize)
+    const uint32_t tile = by * tiles_x + bx;
 
     // candidate faces of this wave's tile: rwr_wf_cull.h (shared with k_wf_classify)
-    const WfWaveCull wc = wf_wave_cull<CULL>(ftris, n_tris, row_begin, bins_enabled, mesh_x0, mesh_y0, mesh_x1, mesh_y1, p.bins, blk_x0,
-                                             row_begin + by * p.row_pitch, wave, lane);
+    const FrameTri *__restrict__ ftris = qi->ftris;
+    const WfWaveCull wc = wf_wave_cull<CULL>(ftris, qi->n_tris, row_begin, qi->bins_enabled, qi->mesh_x0, qi->mesh_y0, qi->mesh_x1, qi->mesh_y1,
+                                             qi->p.bins, blk_x0, row_begin + by * qi->p.row_pitch, wave, lane);
     const uint32_t n_src = wc.n_src;
     const uint32_t *__restrict__ src = wc.src;
     const float tx0 = (float)tile_x0, ty0 = (float)tile_y0;
@@ -171,9 +203,6 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
     const bool cached = wc.cached;
     const unsigned long long cm0 = wc.cm0, cm1 = wc.cm1;
     const uint32_t cf0 = wc.cf0, cf1 = wc.cf1;
-    const float fw = (float)p.width, fh = (float)p.height;
-    const float rw = refined_rcp(fw), rh = refined_rcp(fh);
-    const f3 O = ld3(p.cam.origin);
 
     // the group's sums of E(h0) per pixel as 2^-22 fixed point in 32 bits (a sample's term is clamped to kWfE0Cap = 16 — part of
     // the integrator's definition, rwr_hip.h / oracle render_path_core — so a whole group of <= 64 fits; shifted into the planes'
@@ -187,43 +216,48 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
     // A tile no face and no sphere can be seen through (conservative bounds: nothing any jittered ray of its pixels could
     // hit) has nothing to trace in any sample: its pixels keep the clear values.  On a frame that shows a small mesh
     // that is most tiles.
-    const bool empty_tile = wf_wave_empty<CULL>(wc, p, tx0, ty0);
+    const bool empty_tile = wf_wave_empty<CULL>(wc, qi->p, tx0, ty0);
     if (empty_tile && sample_begin == 0u && z == 0u && in0) {   // sample 0's planes
-        tg.depth[pix0] = 0.0f;
-        if (AUX) { tg.obj_id[pix0] = -1; tg.hit_t[pix0] = 0.0f; }
+        qi->tg.depth[pix0] = 0.0f;
+        if (AUX) { qi->tg.obj_id[pix0] = -1; qi->tg.hit_t[pix0] = 0.0f; }
         if (in1) {
-            tg.depth[pix0 + 1u] = 0.0f;
-            if (AUX) { tg.obj_id[pix0 + 1u] = -1; tg.hit_t[pix0 + 1u] = 0.0f; }
+            qi->tg.depth[pix0 + 1u] = 0.0f;
+            if (AUX) { qi->tg.obj_id[pix0 + 1u] = -1; qi->tg.hit_t[pix0 + 1u] = 0.0f; }
         }
     }
-    if (empty_tile && p.bounces != 0u && lane == 0u && z == 0u)    // nothing emitted: the bounce stage sees empty ballots
+    if (empty_tile && qi->p.bounces != 0u && lane == 0u && z == 0u)    // nothing emitted: the bounce stage sees empty ballots
         for (uint32_t sidx = 0; sidx < sample_count; sidx++) {
-            unsigned long long *mk = wf.masks + (size_t)(tile * wf.group + sidx) * 8u + wave * 2u;
+            unsigned long long *mk = qi->wf.masks + (size_t)(tile * qi->wf.group + sidx) * 8u + wave * 2u;
             mk[0] = 0ull; mk[1] = 0ull;
         }
 
     for (uint32_t sidx = z; sidx < (empty_tile ? 0u : sample_count); sidx += z_split) {
         const uint32_t sample = sample_begin + sidx;
         // -- the sample's ray: pixel centre at spp = 1, else two uniforms of the counter-based RNG ---------------
-        const u2 base = u2{rng_base(pix0, sample, p.seed), rng_base(pix0 + 1u, sample, p.seed)};
+        kernarg<WfPrimaryArgs> *const qr = wf_args_again(ka);   // this phase's kernel arguments: seed, spp, the camera
+        const u2 base = u2{rng_base(pix0, sample, qr->p.seed), rng_base(pix0 + 1u, sample, qr->p.seed)};
         f2 jx = splat(0.5f), jy = splat(0.5f);
-        if (p.spp > 1u) {
+        if (qr->p.spp > 1u) {
             jx = f2{rng_dim(base.x, 0u), rng_dim(base.y, 0u)};
             jy = f2{rng_dim(base.x, 1u), rng_dim(base.y, 1u)};
         }
         const f2 fx = f2{(float)px0, (float)(px0 + 1u)} + jx;
         const f2 fy = splat((float)py) + jy;
-        const v3 D = pixel_pair_ray_dir_at(p.cam, fx, fy, fw, fh, rw, rh);
+        const float fw = (float)qr->p.width, fh = (float)qr->p.height;   // (8 instructions a sample against 4-8 registers across the loop)
+        const v3 D = pixel_pair_ray_dir_at(qr->p.cam, fx, fy, fw, fh, refined_rcp(fw), refined_rcp(fh));
+        const f3 O = ld3(qr->p.cam.origin);
 
         f2 depth_tex = splat(0.0f), win_t = splat(0.0f);
         i2 obj = i2{-1, -1};
         // -- analytic sphere passes, in order (lib.rs:1106-1173) ------------------------------------------------
-        for (uint32_t s = 0; s < p.n_spheres; s++) {
-            if (CULL && ((tx0 + kTileWf < p.sphere_rect[s][0]) || (tx0 > p.sphere_rect[s][2]) ||
-                         (ty0 + kTileHf < p.sphere_rect[s][1]) || (ty0 > p.sphere_rect[s][3])))
+        kernarg<WfPrimaryArgs> *const qs = wf_args_again(ka);   // the spheres and their screen rectangles
+        const uint32_t n_spheres = qs->p.n_spheres;
+        for (uint32_t s = 0; s < n_spheres; s++) {
+            if (CULL && ((tx0 + kTileWf < qs->p.sphere_rect[s][0]) || (tx0 > qs->p.sphere_rect[s][2]) ||
+                         (ty0 + kTileHf < qs->p.sphere_rect[s][1]) || (ty0 > qs->p.sphere_rect[s][3])))
                 continue;
             f2 t = splat(0.0f);
-            const i2 hit = sphere_ray_intersect_t(ld3(p.spheres[s].center), p.spheres[s].radius, O, D, t);
+            const i2 hit = sphere_ray_intersect_t(ld3(qs->p.spheres[s].center), qs->p.spheres[s].radius, O, D, t);
             if (any2(hit)) {
                 const f2 current_depth = 1.0f - depth_tex;  // sphere/compute.wgsl:130
                 const f2 depth = to_non_linear_depth(t);
@@ -242,14 +276,18 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
         ShadeRec last_shade = {};
         // survivors in ascending face order; wave-uniform face index: the record comes in through scalar loads.
         // Samples jitter the ray, never the origin: the plane numerator is the frame's per-face table.
+        kernarg<WfPrimaryArgs> *const qm = wf_args_again(ka);   // the face records, the shading records, the numerators
+        const const_ptr<TriRecord> tris_c = to_const_space(qm->tris);
+        const const_ptr<ShadeRec> shade_c = to_const_space(qm->shade);
+        const const_ptr<float> tnum_c = to_const_space(qm->p.tnum);
         auto walk = [&](unsigned long long m, uint32_t faces_v) {
             while (m) {
                 const uint32_t b = (uint32_t)__builtin_ctzll(m);
                 m &= m - 1ull;
                 const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)faces_v, (int)b);
-                intersect_and_select(tris[idx], p.tnum[idx], idx, O, D, best);
+                intersect_and_select(load_tri_record(tris_c + idx), tnum_c[idx], idx, O, D, best);
                 n_tested++;
-                last_shade = shade[idx];
+                last_shade = load_shade_record(shade_c + idx);
             }
         };
         if (cached) {
@@ -274,11 +312,13 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
             win_t = win ? best.t : win_t;
         }
         if (sample == 0u && in0) {  // depth / aux planes report sample 0
-            tg.depth[pix0] = depth_tex.x;
-            if (AUX) { tg.obj_id[pix0] = obj.x; tg.hit_t[pix0] = win_t.x; }
+            kernarg<WfPrimaryArgs> *const qt = wf_args_again(ka);   // the targets (once per frame and pixel: addresses made here, not kept)
+            float *const depth_plane = qt->tg.depth;
+            depth_plane[pix0] = depth_tex.x;
+            if (AUX) { qt->tg.obj_id[pix0] = obj.x; qt->tg.hit_t[pix0] = win_t.x; }
             if (in1) {
-                tg.depth[pix0 + 1u] = depth_tex.y;
-                if (AUX) { tg.obj_id[pix0 + 1u] = obj.y; tg.hit_t[pix0 + 1u] = win_t.y; }
+                depth_plane[pix0 + 1u] = depth_tex.y;
+                if (AUX) { qt->tg.obj_id[pix0 + 1u] = obj.y; qt->tg.hit_t[pix0 + 1u] = win_t.y; }
             }
         }
 
@@ -287,10 +327,13 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
         f2 tr = splat(0.0f), tgc = splat(0.0f), tb = splat(0.0f);
         if (__any(any2(obj >= 0))) {
             f2 mr, mg, mb, xr, xg, xb;
-            if (NMAP) shade_mesh_pair<true, false, true>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
-            else if (p.n_materials > 1u) shade_mesh_pair<true, false>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
-            else if (n_tested == 1u) shade_mesh_pair<false, true>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
-            else shade_mesh_pair<false, false>(p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
+            kernarg<WfPrimaryArgs> *const qh = wf_args_again(ka);   // material constants, the texture, the shading records
+            const ShadeRec *shade = qh->shade;
+            const float4 *tex = qh->tex;
+            if (NMAP) shade_mesh_pair<true, false, true>(qh->p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
+            else if (qh->p.n_materials > 1u) shade_mesh_pair<true, false>(qh->p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
+            else if (n_tested == 1u) shade_mesh_pair<false, true>(qh->p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
+            else shade_mesh_pair<false, false>(qh->p, shade, tex, obj, last_shade, best, D, mr, mg, mb, xr, xg, xb);
             const i2 is_mesh = obj >= 0;
             cr = is_mesh ? mr : cr; cg = is_mesh ? mg : cg; cb = is_mesh ? mb : cb;
             tr = is_mesh ? xr : tr; tgc = is_mesh ? xg : tgc; tb = is_mesh ? xb : tb;
@@ -303,7 +346,7 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
                 const int o = k ? obj.y : obj.x;
                 if (o < -1) {
                     const f3 Dk = lane3(D, k);
-                    const f3 center = ld3(p.spheres[-2 - o].center);
+                    const f3 center = ld3(wf_args_again(ka)->p.spheres[-2 - o].center);
                     const f3 P = along(O, k ? win_t.y : win_t.x, Dk);
                     const f3 c = shade_sphere(cnormalize(sub3(P, center)), Dk);
                     const f3 ne = normalize3(sub3(P, center));
@@ -325,12 +368,15 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
         }
 
         // -- bounce ray of every pixel that hit something ----------------------------------------------------------
-        if (p.bounces != 0u) {
+        kernarg<WfPrimaryArgs> *const qb = wf_args_again(ka);   // the ray queue
+        if (qb->p.bounces != 0u) {
+            const uint32_t wf_group = qb->wf.group;
+            const TriRecord *tris = qb->tris;
             const i2 emit = hit & i2{in0 ? -1 : 0, in1 ? -1 : 0};
             const unsigned long long m0 = __ballot(emit.x != 0), m1 = __ballot(emit.y != 0);
-            const uint32_t slot_base = (tile * wf.group + sidx) * kWfTilePixels + wave * 128u;
+            const uint32_t slot_base = (tile * wf_group + sidx) * kWfTilePixels + wave * 128u;
             if (lane == 0u) {
-                unsigned long long *mk = wf.masks + (size_t)(tile * wf.group + sidx) * 8u + wave * 2u;
+                unsigned long long *mk = qb->wf.masks + (size_t)(tile * wf_group + sidx) * 8u + wave * 2u;
                 mk[0] = m0; mk[1] = m1;
             }
             emitted += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
@@ -348,17 +394,20 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
                 const v3 P = along(splat3(O), win_t, D);
                 const v3 O1 = v3{P.x + n.x * 1e-4f, P.y + n.y * 1e-4f, P.z + n.z * 1e-4f};
                 const v3 D1 = bounce_direction_pair(n, base, emit);
+                kernarg<WfPrimaryArgs> *const qq = wf_args_again(ka);   // where the rays go
+                float4 *const rays = qq->wf.rays;
+                uint16_t *const bins = qq->wf.bins;
                 if (emit.x) {
                     const uint32_t slot = slot_base + lane;
-                    wf.rays[2u * slot] = make_float4(O1.x.x, O1.y.x, O1.z.x, wf_pack_unorm16x2(tr.x, tgc.x));
-                    wf.rays[2u * slot + 1u] = make_float4(D1.x.x, D1.y.x, D1.z.x, wf_pack_unorm16x2(tb.x, 0.0f));
-                    wf.bins[slot] = (uint16_t)wf_direction_bin(lane3(D1, 0));
+                    rays[2u * slot] = make_float4(O1.x.x, O1.y.x, O1.z.x, wf_pack_unorm16x2(tr.x, tgc.x));
+                    rays[2u * slot + 1u] = make_float4(D1.x.x, D1.y.x, D1.z.x, wf_pack_unorm16x2(tb.x, 0.0f));
+                    bins[slot] = (uint16_t)wf_direction_bin(lane3(D1, 0));
                 }
                 if (emit.y) {
                     const uint32_t slot = slot_base + 64u + lane;
-                    wf.rays[2u * slot] = make_float4(O1.x.y, O1.y.y, O1.z.y, wf_pack_unorm16x2(tr.y, tgc.y));
-                    wf.rays[2u * slot + 1u] = make_float4(D1.x.y, D1.y.y, D1.z.y, wf_pack_unorm16x2(tb.y, 0.0f));
-                    wf.bins[slot] = (uint16_t)wf_direction_bin(lane3(D1, 1));
+                    rays[2u * slot] = make_float4(O1.x.y, O1.y.y, O1.z.y, wf_pack_unorm16x2(tr.y, tgc.y));
+                    rays[2u * slot + 1u] = make_float4(D1.x.y, D1.y.y, D1.z.y, wf_pack_unorm16x2(tb.y, 0.0f));
+                    bins[slot] = (uint16_t)wf_direction_bin(lane3(D1, 1));
                 }
             }
         }
@@ -366,21 +415,23 @@ k_wf_primary(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_b
 
     // -- the frame's fixed-point sums: once per group and pixel (plain read-modify-write when this workgroup owns the tile's
     // samples alone, integer atomics when it shares them: the same bits either way) ------------------------------------------
+    kernarg<WfPrimaryArgs> *const qf = wf_args_again(ka);   // the frame's planes
     if (in0 && !empty_tile) {
-        const size_t plane = (size_t)p.width * p.height;
+        unsigned long long *const fix = qf->wf.fix;
+        const size_t plane = (size_t)qf->p.width * qf->p.height;
         const unsigned long long fa0 = (unsigned long long)hits0 * (unsigned long long)(2.0f * kWfFixedScale);
         const unsigned long long fa1 = (unsigned long long)hits1 * (unsigned long long)(2.0f * kWfFixedScale);
         const unsigned long long r0 = (unsigned long long)fr0 << 4, g0 = (unsigned long long)fg0 << 4, b0 = (unsigned long long)fb0 << 4;
         const unsigned long long r1 = (unsigned long long)fr1 << 4, g1 = (unsigned long long)fg1 << 4, b1 = (unsigned long long)fb1 << 4;
-        if (!LIST && z_split == 1u && !wf.shared_planes) {
-            wf.fix[pix0] += r0; wf.fix[plane + pix0] += g0; wf.fix[2u * plane + pix0] += b0; wf.fix[3u * plane + pix0] += fa0;
-            if (in1) { wf.fix[pix0 + 1u] += r1; wf.fix[plane + pix0 + 1u] += g1; wf.fix[2u * plane + pix0 + 1u] += b1; wf.fix[3u * plane + pix0 + 1u] += fa1; }
+        if (!LIST && z_split == 1u && !qf->wf.shared_planes) {
+            fix[pix0] += r0; fix[plane + pix0] += g0; fix[2u * plane + pix0] += b0; fix[3u * plane + pix0] += fa0;
+            if (in1) { fix[pix0 + 1u] += r1; fix[plane + pix0 + 1u] += g1; fix[2u * plane + pix0 + 1u] += b1; fix[3u * plane + pix0 + 1u] += fa1; }
         } else {
-            if (hits0) { atomicAdd(&wf.fix[pix0], r0); atomicAdd(&wf.fix[plane + pix0], g0); atomicAdd(&wf.fix[2u * plane + pix0], b0); atomicAdd(&wf.fix[3u * plane + pix0], fa0); }
-            if (in1 && hits1) { atomicAdd(&wf.fix[pix0 + 1u], r1); atomicAdd(&wf.fix[plane + pix0 + 1u], g1); atomicAdd(&wf.fix[2u * plane + pix0 + 1u], b1); atomicAdd(&wf.fix[3u * plane + pix0 + 1u], fa1); }
+            if (hits0) { atomicAdd(&fix[pix0], r0); atomicAdd(&fix[plane + pix0], g0); atomicAdd(&fix[2u * plane + pix0], b0); atomicAdd(&fix[3u * plane + pix0], fa0); }
+            if (in1 && hits1) { atomicAdd(&fix[pix0 + 1u], r1); atomicAdd(&fix[plane + pix0 + 1u], g1); atomicAdd(&fix[2u * plane + pix0 + 1u], b1); atomicAdd(&fix[3u * plane + pix0 + 1u], fa1); }
         }
     }
-    if (lane == 0u && emitted) atomicAdd(wf.wave_total + tile * 4u + wave, emitted);   // (zeroed when the frame starts)
+    if (lane == 0u && emitted) atomicAdd(qf->wf.wave_total + tile * 4u + wave, emitted);   // (zeroed when the frame starts)
     } while (LIST);
 }
 
@@ -393,8 +444,9 @@ hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriReco
     const dim3 grid((fp.width + kWfTileW - 1u) / kWfTileW, band_strips(fp), z_split);
     const dim3 block(256);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0, do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
-#define RWR_WF_ARGS ftris, fp.n_tris, fp.row_begin, fp.bins.enabled, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], \
-                    sample_begin, sample_count, z_split, fp, tris, shade, tex, tg, wf
+    const WfPrimaryArgs args{ftris, fp.n_tris, fp.row_begin, fp.bins.enabled, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3],
+                             sample_begin, sample_count, z_split, fp, tris, shade, tex, tg, wf};
+#define RWR_WF_ARGS args
     const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0;
 #define RWR_WF_LAUNCH(A, C, N) hipLaunchKernelGGL((k_wf_primary<A, C, N>), grid, block, 0, s, RWR_WF_ARGS)
     if (wf.live_list && do_cull) {   // item after item of (live tile) x (share of its samples)

@@ -17,8 +17,11 @@ namespace rwr {
 // (tr, tg, tb): the filtered diffuse texel of each pixel — the surface's albedo, which the wavefront integrator
 // carries along the bounce ray.
 // NMAP: normal-mapped light terms where the face's material has a map (extension, RWR_FLAG_NORMAL_MAP).
-template <bool MULTI, bool UNIFORM, bool NMAP = false>
-RWR_DEV void shade_mesh_pair(const FrameParams &p, const ShadeRec *__restrict__ shade, const float4 *__restrict__ tex,
+// P: FrameParams, or FrameParams in the kernel-argument (constant) address space — a caller inside a long loop reads the fields
+// through a pointer it has just re-derived, so that they are loaded where they are used instead of living in scalar registers
+// for the whole loop (kernels_wf_primary.hip).
+template <bool MULTI, bool UNIFORM, bool NMAP = false, typename P = FrameParams>
+RWR_DEV void shade_mesh_pair(const P &p, const ShadeRec *__restrict__ shade, const float4 *__restrict__ tex,
                              i2 obj, const ShadeRec &uS, const MeshHit2 &best, v3 D, f2 &cr, f2 &cg, f2 &cb,
                              f2 &tr, f2 &tg, f2 &tb)
 {
@@ -78,8 +81,8 @@ RWR_DEV void shade_mesh_pair(const FrameParams &p, const ShadeRec *__restrict__ 
     cb = fma2(ksb, sp, fma2(tb, ndl, kab));
 }
 
-template <bool MULTI, bool UNIFORM, bool NMAP = false>
-RWR_DEV void shade_mesh_pair(const FrameParams &p, const ShadeRec *__restrict__ shade, const float4 *__restrict__ tex,
+template <bool MULTI, bool UNIFORM, bool NMAP = false, typename P = FrameParams>
+RWR_DEV void shade_mesh_pair(const P &p, const ShadeRec *__restrict__ shade, const float4 *__restrict__ tex,
                              i2 obj, const ShadeRec &uS, const MeshHit2 &best, v3 D, f2 &cr, f2 &cg, f2 &cb)
 {
     f2 tr, tg, tb;

@@ -16,9 +16,9 @@ struct WfWaveCull {
 };
 
 // blk_x0, blk_y0: the 64x8-pixel block's first pixel (blk_y0 includes row_begin); wave: 0..3 inside the block
-template <bool CULL>
+template <bool CULL, typename Bins = BinGrid>   // (Bins: BinGrid, possibly in the kernel-argument address space)
 RWR_DEV WfWaveCull wf_wave_cull(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_begin, uint32_t bins_enabled,
-                                int32_t mesh_x0, int32_t mesh_y0, int32_t mesh_x1, int32_t mesh_y1, const BinGrid &bins,
+                                int32_t mesh_x0, int32_t mesh_y0, int32_t mesh_x1, int32_t mesh_y1, const Bins &bins,
                                 uint32_t blk_x0, uint32_t blk_y0, uint32_t wave, uint32_t lane)
 {
     WfWaveCull c;
@@ -63,8 +63,8 @@ RWR_DEV WfWaveCull wf_wave_cull(const FrameTri *__restrict__ ftris, uint32_t n_t
 // A tile no face and no sphere can be seen through (conservative bounds: nothing any jittered ray of its pixels could
 // hit) has nothing to trace in any sample: its pixels keep the clear values.  On a frame that shows a small mesh
 // that is most tiles.  Wave-uniform.
-template <bool CULL>
-RWR_DEV bool wf_wave_empty(const WfWaveCull &c, const FrameParams &p, float tx0, float ty0)
+template <bool CULL, typename P = FrameParams>
+RWR_DEV bool wf_wave_empty(const WfWaveCull &c, const P &p, float tx0, float ty0)
 {
     bool empty_tile = CULL && (c.n_src == 0u || (c.cached && (c.cm0 | c.cm1) == 0ull));
     if (empty_tile)
