@@ -988,7 +988,7 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
             RWR_HIP_CHECK(sl.d_bin_offsets.ensure(n_bins));
             RWR_HIP_CHECK(sl.d_bin_total.ensure(1));
             RWR_HIP_CHECK(launch_bin_faces(stream, sl.d_ftris.ptr, ctx->n_tris, row_begin, sl.d_bin_lists.ptr, sl.d_bin_counts.ptr,
-                                           sl.d_bin_offsets.ptr, sl.d_bin_total.ptr, bins_x, bins_y, (uint32_t)sl.d_bin_lists.count));
+                                           sl.d_bin_offsets.ptr, sl.d_bin_total.ptr, bins_x, bins_y, (uint32_t)sl.d_bin_lists.count, fp.mesh_px));
             RWR_HIP_CHECK(hipMemcpyAsync(sl.h_bin_total, sl.d_bin_total.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             fp.bins = BinGrid{sl.d_bin_lists.ptr, sl.d_bin_counts.ptr + 4u * (size_t)n_bins, sl.d_bin_offsets.ptr, bins_x, bins_y, (uint32_t)sl.d_bin_lists.count, 1u};
         }

@@ -202,10 +202,19 @@ hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const rwr_cam
 template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_bin_faces(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *__restrict__ lists,
-            uint32_t *__restrict__ counts4, const uint32_t *__restrict__ offsets, uint32_t bins_x)
+            uint32_t *__restrict__ counts4, const uint32_t *__restrict__ offsets, uint32_t bins_x, int32_t mesh_x0, int32_t mesh_y0,
+            int32_t mesh_x1, int32_t mesh_y1)
 {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     const uint32_t bin = blockIdx.y * bins_x + blockIdx.x;
+    {   // a bin outside the screen rectangle of the whole mesh (FrameParams::mesh_px: the render kernels skip the mesh pass for every
+        // tile of it and never look at its list) has nothing to walk: on a frame that shows a small mesh that is most bins
+        const int32_t bx0 = (int32_t)(blockIdx.x * kBinW), by0 = (int32_t)(row_begin + blockIdx.y * kBinH);
+        if (bx0 + (int32_t)kBinW < mesh_x0 || bx0 > mesh_x1 || by0 + (int32_t)kBinH < mesh_y0 || by0 > mesh_y1) {
+            if (!FILL && lane == 0u) counts4[bin * 4u + wave] = 0u;
+            return;
+        }
+    }
     const uint32_t quarter = ((n_tris + 255u) / 256u) * 64u;
     const uint32_t begin = wave * quarter, end = min(n_tris, begin + quarter);
     uint32_t *__restrict__ out = nullptr;
@@ -277,14 +286,17 @@ k_bin_scan(const uint32_t *__restrict__ counts4, uint32_t *__restrict__ counts, 
 }
 
 hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *lists,
-                            uint32_t *counts, uint32_t *offsets, uint32_t *total_out, uint32_t bins_x, uint32_t bins_y, uint32_t capacity)
+                            uint32_t *counts, uint32_t *offsets, uint32_t *total_out, uint32_t bins_x, uint32_t bins_y, uint32_t capacity,
+                            const int32_t mesh_px[4])
 {
     if (n_tris == 0 || bins_x == 0 || bins_y == 0) return hipSuccess;
     uint32_t *counts4 = counts;                      // the counts buffer: four per bin (one per wave, 16-byte groups) ...
     counts += 4u * (size_t)bins_x * bins_y;          // ... then the bins' own counts, which the render kernels read
-    hipLaunchKernelGGL((k_bin_faces<false>), dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts4, offsets, bins_x);
+    hipLaunchKernelGGL((k_bin_faces<false>), dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts4, offsets, bins_x,
+                       mesh_px[0], mesh_px[1], mesh_px[2], mesh_px[3]);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, counts4, counts, offsets, total_out, bins_x * bins_y, capacity);
-    hipLaunchKernelGGL((k_bin_faces<true>), dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts4, offsets, bins_x);
+    hipLaunchKernelGGL((k_bin_faces<true>), dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts4, offsets, bins_x,
+                       mesh_px[0], mesh_px[1], mesh_px[2], mesh_px[3]);
     return hipGetLastError();
 }
 

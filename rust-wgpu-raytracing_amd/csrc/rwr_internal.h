@@ -310,7 +310,8 @@ hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const rwr_cam
                               const FrameSetupOut &out);
 // count -> scan -> fill; *total_out (device) receives the entries the frame's lists need
 hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *lists,
-                            uint32_t *counts, uint32_t *offsets, uint32_t *total_out, uint32_t bins_x, uint32_t bins_y, uint32_t capacity);
+                            uint32_t *counts, uint32_t *offsets, uint32_t *total_out, uint32_t bins_x, uint32_t bins_y, uint32_t capacity,
+                            const int32_t mesh_px[4]);
 hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                           const FrameTri *ftris, const float4 *tex, const Targets &tg);
 

@@ -344,6 +344,41 @@ int main(int argc, char **argv)
                    S, nb * nb, (double)c / nr, (double)pk_n / pk_w, (double)pk_f / pk_w, (double)pk_cost / nr);
         }
     }
+    // policy D: ray STREAM traversal — per pool (tile x S samples) and octant, every BVH node / leaf face is visited ONCE with the list
+    // of the pool's rays that reach it (wave-uniform node, rays 64 at a time, compaction into the children's lists); priced per
+    // chunk of 64 rays: node 80, face 100 wave instructions (+ list upkeep), rays visit what they visit in their own traversal
+    if (S > 1) {
+        const int tw = argc > 4 ? atoi(argv[4]) : 64, th = argc > 5 ? atoi(argv[5]) : 8;
+        for (int chunk : {64, 128}) {
+            long cost = 0, full = 0; size_t nr = 0, nlists = 0; double fill = 0;
+            for (int by = 0; by < rows; by += th)
+                for (int bx = 0; bx < w; bx += tw) {
+                    std::vector<uint32_t> cn[8], cf[8];
+                    for (int o = 0; o < 8; o++) { cn[o].assign(bvh.nodes.size(), 0); cf[o].assign(bvh.leaf_faces.size() + 8, 0); }
+                    for (int sidx = 0; sidx < S; sidx++)
+                        for (int y = by; y < std::min(rows, by + th); y++)
+                            for (int x = bx; x < std::min(w, bx + tw); x++) {
+                                const size_t i = (size_t)y * w + x;
+                                if (!hit[i]) continue;
+                                const float *R = &rays[((size_t)sidx * rows * w + i) * 6];
+                                const float *D = R + 3;
+                                const int o = (D[0] < 0) | ((D[1] < 0) << 1) | ((D[2] < 0) << 2);
+                                const RayTrace rt = trace(bvh, R, D);
+                                nr++;
+                                for (auto &st : rt.steps) {
+                                    if (st.kind == 0) cn[o][st.id]++;
+                                    else for (int k = 0; k < st.nf; k++) cf[o][st.id + k]++;
+                                }
+                            }
+                    for (int o = 0; o < 8; o++) {
+                        for (auto n : cn[o]) if (n) { const long c = (n + chunk - 1) / chunk; cost += c * (chunk == 64 ? 80 : 110); full += c; fill += n; nlists++; }
+                        for (auto n : cf[o]) if (n) { const long c = (n + chunk - 1) / chunk; cost += c * (chunk == 64 ? 100 : 150); full += c; fill += n; nlists++; }
+                    }
+                }
+            printf("ray stream, %dx%d tiles x %d samples, chunks of %3d rays: %8.1f wave-instr per ray (+ set-up); %.1f lists per pool-octant, mean chunk fill %.0f %%\n",
+                   tw, th, S, chunk, (double)cost / nr, (double)nlists / ((rows / th) * (w / tw) * 8.0), 100.0 * fill / ((double)full * chunk));
+        }
+    }
     // policy F: pool = all rays of the band that START ON THE SAME FACE (whatever tile their pixel is in), sorted by direction bin
     if (S > 1) {
         std::vector<int32_t> objv((size_t)rows * w, -1);
