@@ -98,7 +98,7 @@ def test_world_of_one_strip_gather_equals_readback(rwr, suzanne):
         ctx.dist_destroy()
 
 
-@pytest.mark.parametrize("frames_in_flight", [1, 2])
+@pytest.mark.parametrize("frames_in_flight", [1, 2, 3])
 def test_world_of_one_strip_gather_with_frames_in_flight(rwr, suzanne, frames_in_flight):
     """Every frame slot owns its gather set: gathers of consecutive frames overlap the next render, each frame still arrives
     whole (checked frame by frame against a plain render of the same camera)."""

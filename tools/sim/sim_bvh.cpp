@@ -344,17 +344,18 @@ int main(int argc, char **argv)
                    S, nb * nb, (double)c / nr, (double)pk_n / pk_w, (double)pk_f / pk_w, (double)pk_cost / nr);
         }
     }
-    // policy D: ray STREAM traversal — per pool (tile x S samples) and octant, every BVH node / leaf face is visited ONCE with the list
-    // of the pool's rays that reach it (wave-uniform node, rays 64 at a time, compaction into the children's lists); priced per
-    // chunk of 64 rays: node 80, face 100 wave instructions (+ list upkeep), rays visit what they visit in their own traversal
+    // policy D: ray STREAM traversal — per pool (tile x S samples), octant and BATCH of B direction-sorted rays, every BVH node / leaf
+    // face is visited ONCE with the list of the batch's rays that reach it (wave-uniform node, rays 64 at a time, compaction into
+    // the children's lists); priced per chunk of 64 rays: node 80, face 100 wave instructions (+ list upkeep); rays visit what they
+    // visit in their own traversal
     if (S > 1) {
         const int tw = argc > 4 ? atoi(argv[4]) : 64, th = argc > 5 ? atoi(argv[5]) : 8;
-        for (int chunk : {64, 128}) {
-            long cost = 0, full = 0; size_t nr = 0, nlists = 0; double fill = 0;
+        for (int B : {256, 512, 1024, 1 << 20}) {
+            long cost = 0, full = 0; size_t nr = 0; double fill = 0; size_t max_arena = 0;
             for (int by = 0; by < rows; by += th)
                 for (int bx = 0; bx < w; bx += tw) {
-                    std::vector<uint32_t> cn[8], cf[8];
-                    for (int o = 0; o < 8; o++) { cn[o].assign(bvh.nodes.size(), 0); cf[o].assign(bvh.leaf_faces.size() + 8, 0); }
+                    struct E { int key; RayTrace r; };
+                    std::vector<E> oct[8];
                     for (int sidx = 0; sidx < S; sidx++)
                         for (int y = by; y < std::min(rows, by + th); y++)
                             for (int x = bx; x < std::min(w, bx + tw); x++) {
@@ -363,20 +364,29 @@ int main(int argc, char **argv)
                                 const float *R = &rays[((size_t)sidx * rows * w + i) * 6];
                                 const float *D = R + 3;
                                 const int o = (D[0] < 0) | ((D[1] < 0) << 1) | ((D[2] < 0) << 2);
-                                const RayTrace rt = trace(bvh, R, D);
+                                const float l1 = std::fabs(D[0]) + std::fabs(D[1]) + std::fabs(D[2]);
+                                const int iu = std::min(15, (int)(std::fabs(D[0]) / l1 * 16)), iv = std::min(15, (int)(std::fabs(D[1]) / l1 * 16));
+                                oct[o].push_back({iv * 16 + iu, trace(bvh, R, D)});
                                 nr++;
-                                for (auto &st : rt.steps) {
-                                    if (st.kind == 0) cn[o][st.id]++;
-                                    else for (int k = 0; k < st.nf; k++) cf[o][st.id + k]++;
-                                }
                             }
                     for (int o = 0; o < 8; o++) {
-                        for (auto n : cn[o]) if (n) { const long c = (n + chunk - 1) / chunk; cost += c * (chunk == 64 ? 80 : 110); full += c; fill += n; nlists++; }
-                        for (auto n : cf[o]) if (n) { const long c = (n + chunk - 1) / chunk; cost += c * (chunk == 64 ? 100 : 150); full += c; fill += n; nlists++; }
+                        std::stable_sort(oct[o].begin(), oct[o].end(), [](const E &a, const E &b) { return a.key < b.key; });
+                        for (size_t base = 0; base < oct[o].size(); base += (size_t)B) {
+                            std::vector<uint32_t> cn(bvh.nodes.size(), 0), cf(bvh.leaf_faces.size() + 8, 0);
+                            size_t visits = 0;
+                            for (size_t e = base; e < std::min(oct[o].size(), base + (size_t)B); e++)
+                                for (auto &st : oct[o][e].r.steps) {
+                                    if (st.kind == 0) { cn[st.id]++; visits++; }
+                                    else for (int k = 0; k < st.nf; k++) cf[st.id + k]++;
+                                }
+                            max_arena = std::max(max_arena, visits);
+                            for (auto n : cn) if (n) { const long c = (n + 63) / 64; cost += c * 80; full += c; fill += n; }
+                            for (auto n : cf) if (n) { const long c = (n + 63) / 64; cost += c * 100; full += c; fill += n; }
+                        }
                     }
                 }
-            printf("ray stream, %dx%d tiles x %d samples, chunks of %3d rays: %8.1f wave-instr per ray (+ set-up); %.1f lists per pool-octant, mean chunk fill %.0f %%\n",
-                   tw, th, S, chunk, (double)cost / nr, (double)nlists / ((rows / th) * (w / tw) * 8.0), 100.0 * fill / ((double)full * chunk));
+            printf("ray stream, %dx%d tiles x %d samples, batches of %7d rays of an octant: %8.1f wave-instr per ray (+ set-up), mean chunk fill %.0f %%, most list entries a batch makes in all %zu\n",
+                   tw, th, S, B, (double)cost / nr, 100.0 * fill / ((double)full * 64), max_arena);
         }
     }
     // policy F: pool = all rays of the band that START ON THE SAME FACE (whatever tile their pixel is in), sorted by direction bin
