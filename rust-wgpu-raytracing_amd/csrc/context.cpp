@@ -132,6 +132,7 @@ struct rwr_context {
     float bvh_leaf_extent = 0.0f;
     float wf_packet_extent = 0.5f;   // x mean leaf extent; tunable: RWR_WF_PACKET_EXTENT
     uint32_t wf_min_packet_pools = 128;   // tunable: RWR_WF_MIN_PACKET_POOLS
+    uint32_t wf_lane_items = 16384;       // tunable: RWR_WF_LANE_ITEMS
     float aabb_lo[3] = {0, 0, 0}, aabb_hi[3] = {0, 0, 0};   // of the (flattened) world-space faces
     float auto_bvh_face_px = 150.0f;   // tunable: RWR_AUTO_BVH_FACE_PX (0 = never pick the BVH kernel by itself)
     // wavefront integrator: tunables and what the host remembers of the last frame
@@ -540,6 +541,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     }
     if (const char *e13 = std::getenv("RWR_WF_OVERLAP")) ctx->wf_queues = std::min(rwr_context::kWfMaxQueues, std::max(1u, (uint32_t)std::strtoul(e13, nullptr, 10)));
     if (const char *e12 = std::getenv("RWR_WF_ZSPLIT")) ctx->wf_z_split = (uint32_t)std::strtoul(e12, nullptr, 10);
+    if (const char *e15 = std::getenv("RWR_WF_LANE_ITEMS")) ctx->wf_lane_items = std::max(1u, (uint32_t)std::strtoul(e15, nullptr, 10));
     if (const char *e10 = std::getenv("RWR_WF_MIN_PACKET_POOLS")) ctx->wf_min_packet_pools = (uint32_t)std::strtoul(e10, nullptr, 10);
     if (const char *e8 = std::getenv("RWR_WF_PACKET_EXTENT")) ctx->wf_packet_extent = (float)std::atof(e8);
     if (const char *e7 = std::getenv("RWR_WF_PACKET_FILL")) ctx->wf_packet_fill = (float)std::atof(e7);
@@ -1019,7 +1021,7 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
         RWR_HIP_CHECK(launch_primary_dormant(stream, fp, st, ctx->d_tris.ptr, ctx->d_shade.ptr, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront && ((rp.flags & RWR_FLAG_USE_BVH) || auto_bvh)) {
-        const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u, 0.0f, 0u};
+        const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u, 0.0f, 0u, 0u};
         RWR_HIP_CHECK(launch_primary_bvh(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh_p, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront) {
@@ -1121,7 +1123,7 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
                                rp.max_bounces ? W.d_live.ptr + h * 4u : nullptr, overlap ? 1u : 0u, live_list, live_count, tile_live};
         }
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u,
-                            ctx->wf_packet_extent * ctx->bvh_leaf_extent, ctx->wf_min_packet_pools};
+                            ctx->wf_packet_extent * ctx->bvh_leaf_extent, ctx->wf_min_packet_pools, ctx->wf_lane_items};
         if (overlap) {   // the other streams start behind this frame's setup (and so behind the previous frame's resolve)
             RWR_HIP_CHECK(hipEventRecord(W.fork, stream));
             for (size_t q = 1; q < n_queues; q++) RWR_HIP_CHECK(hipStreamWaitEvent(W.streams[q], W.fork, 0));

@@ -51,7 +51,6 @@ struct PoolInfo {
 static_assert(sizeof(PoolInfo) == 48, "PoolInfo is 48 B");
 
 constexpr uint32_t kWfMaxSplit = 32;       // at most this many work items share one pool
-constexpr uint32_t kWfTargetItems = 16384; // work items a trace launch should have (64 per CU: one 256-ray chunk each when pools are few)
 constexpr uint32_t kWfWholePools = 1024;   // this many live pools keep the chip busy by themselves
 constexpr uint32_t kWfTargetItemsDense = 4096;
 constexpr uint32_t kWfTraceGroups = 2048;  // workgroups of a trace launch (persistent: they pull work items)
@@ -72,14 +71,14 @@ RWR_DEV float key_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ?
 // Into how many work items a pool of a class with `live` pools in this launch group is cut: one when the frame
 // keeps the chip busy by itself, up to kWfMaxSplit when only a few tiles see anything (a small mesh on an empty
 // screen: otherwise four waves would walk through a pool of thousands of rays one after the other while 250 CUs idle).
-RWR_DEV uint32_t pool_split(uint32_t live, bool packets)
+RWR_DEV uint32_t pool_split(uint32_t live, bool packets, uint32_t lane_items)
 {
     if (live == 0u) return 1u;
     // just enough pieces that every workgroup gets a few items and the last round is short: every share zeroes and flushes
     // 12 KiB of sums (measured at configs[2], 4 050 packet pools: two shares beat one by 8 % and five by 6 %; a 135-row band
     // of the same frame, 510 packet pools: 8 shares, not 32 — 2.9 -> 1.9 ms).  Few pools of the per-lane class (a small mesh on
     // an empty screen: their rays are few, the traversals long): one 256-ray chunk per item.
-    const uint32_t target = (packets || live >= kWfWholePools) ? kWfTargetItemsDense : kWfTargetItems;
+    const uint32_t target = (packets || live >= kWfWholePools) ? kWfTargetItemsDense : lane_items;
     return min(kWfMaxSplit, max(1u, (target + live - 1u) / live));
 }
 
@@ -299,14 +298,14 @@ RWR_DEV void flush_pool(TraceShared &sh, const FrameParams &p, const WfBuffers &
 // — from a device counter until the class's live x split items are handed out.  Returns false when none are left.
 // Contains barriers; uniform over the workgroup.
 RWR_DEV bool next_item(TraceShared &sh, const PoolInfo *__restrict__ info, uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list,
-                       uint32_t n_tiles, uint32_t want_packets, uint32_t min_packet_pools, uint32_t &tile, uint32_t &share,
+                       uint32_t n_tiles, uint32_t want_packets, uint32_t min_packet_pools, uint32_t lane_items, uint32_t &tile, uint32_t &share,
                        uint32_t &n_shares, PoolInfo &pi)
 {
     const uint32_t live_p = counters[kLivePackets], live_l = counters[kLiveLane];
     const bool demote = live_p < min_packet_pools;
     if (want_packets && demote) return false;
     const uint32_t live = want_packets ? live_p : live_l + (demote ? live_p : 0u);
-    n_shares = pool_split(live, want_packets != 0u);
+    n_shares = pool_split(live, want_packets != 0u, lane_items);
     __syncthreads();   // everybody is done with the previous item (sh.item, sh.acc)
     if (threadIdx.x == 0u) sh.item = atomicAdd(&counters[(want_packets ? kWorkPackets : kWorkLane)], 1u);
     __syncthreads();
@@ -351,7 +350,7 @@ k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const S
     bool staged = false;
     uint32_t tile, share, n_shares;
     PoolInfo pi;
-    while (next_item(sh, info, counters, pool_list, n_tiles, 0u, bvh.min_packet_pools, tile, share, n_shares, pi)) {
+    while (next_item(sh, info, counters, pool_list, n_tiles, 0u, bvh.min_packet_pools, bvh.lane_items, tile, share, n_shares, pi)) {
         const uint32_t n_rays = pi.n_rays;
         if (share * 256u >= n_rays) continue;   // uniform
         if (NODES_IN_LDS && !staged) {
@@ -361,10 +360,22 @@ k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const S
             staged = true;
         }
         for (uint32_t i = tid; i < kWfTilePixels * 3u; i += 256u) sh.acc[i] = 0ull;
+        if (tid == 0u) sh.next_packet = 0u;
         __syncthreads();
         const size_t pool_base = (size_t)tile * wf.group * kWfTilePixels;
         const uint16_t *__restrict__ sorted = wf.sorted + pool_base;
-        for (uint32_t i = share * 256u + tid; i < n_rays; i += 256u * n_shares) {   // chunks of 256 sorted rays, dealt round-robin
+        // The item's rays: chunks share, share + n_shares, ... of 256 sorted rays.  Its waves take them 64 rays at a time from a
+        // counter in LDS: a wave whose rays had short traversals goes on with the next 64 instead of waiting for the others at
+        // a barrier (traversal lengths differ several-fold between waves of sparse pools).
+        const uint32_t n_chunks = (n_rays + 255u) / 256u;
+        const uint32_t n_sub = share < n_chunks ? 4u * ((n_chunks - share + n_shares - 1u) / n_shares) : 0u;
+        for (;;) {
+            uint32_t j = 0u;
+            if ((tid & 63u) == 0u) j = atomicAdd(&sh.next_packet, 1u);
+            j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+            if (j >= n_sub) break;
+            const uint32_t i = (share + (j >> 2) * n_shares) * 256u + (j & 3u) * 64u + (tid & 63u);
+            if (i >= n_rays) continue;
             const uint32_t e = sorted[i];
             const float4 a = wf.rays[2u * (pool_base + e)], b = wf.rays[2u * (pool_base + e) + 1u];   // one 32-byte record
             const f3 O = mk3(a.x, a.y, a.z), D = mk3(b.x, b.y, b.z);
@@ -489,7 +500,7 @@ k_wf_trace_packet(const FrameParams p, const TriRecord *__restrict__ tris, const
     const const_ptr<TriRecord> tris_c = to_const_space(tris);
     uint32_t tile, share, n_shares;
     PoolInfo pi;
-    while (next_item(sh, info, counters, pool_list, n_tiles, 1u, bvh.min_packet_pools, tile, share, n_shares, pi)) {
+    while (next_item(sh, info, counters, pool_list, n_tiles, 1u, bvh.min_packet_pools, bvh.lane_items, tile, share, n_shares, pi)) {
     // packets never straddle an octant: packet q of octant o covers sorted[oct_begin[o] + 128 q ...)
     uint32_t n_packets = 0;
 #pragma unroll

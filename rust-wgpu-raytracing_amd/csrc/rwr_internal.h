@@ -245,6 +245,7 @@ struct BvhDevice {
     uint32_t stack_depth;  // 3 * tree depth + 2
     float packet_extent;   // pools whose ray origins span less than this are traced as packets (kernels_wf_bounce.hip)
     uint32_t min_packet_pools;  // fewer packet pools than this in a launch group: the per-lane kernel traces them
+    uint32_t lane_items;        // work items the per-lane kernel's launch should have when pools are few (pool_split; tunable)
 };
 
 hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
