@@ -928,6 +928,16 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
     so.ftris = sl.d_ftris.ptr; so.tnum = sl.d_tnum.ptr;
     so.ray_colp = sl.d_ray_colp.ptr; so.ray_row = sl.d_ray_row.ptr;
     fp.ray_colp = so.ray_colp; fp.ray_row = so.ray_row; fp.tnum = so.tnum;
+    if (rp.spp != 1 || rp.max_bounces != 0) {
+        // the wavefront integrator's per-tile ray counts and live-tile count start every frame from zero: k_frame_setup zeroes them
+        rwr_context::WfState &W0 = ctx->wf_state[ctx->n_slots > 1u ? ctx->cur : 0u];
+        fp.row_begin = row_begin; fp.row_end = row_end; fp.row_pitch = row_pitch;
+        const size_t n_tiles0 = (size_t)((ctx->screen.width + kWfTileW - 1u) / kWfTileW) * band_strips(fp);
+        RWR_HIP_CHECK(W0.d_wave_total.ensure(n_tiles0 * 4u));
+        RWR_HIP_CHECK(W0.d_tiles.ensure(2u * n_tiles0 + 1u));
+        so.zero_a = W0.d_wave_total.ptr; so.n_zero_a = (uint32_t)(n_tiles0 * 4u);
+        so.zero_b = W0.d_tiles.ptr + 2u * n_tiles0; so.n_zero_b = 1u;   // live_count (below)
+    }
     // A/B (RWR_FRAME_GRAPH=1): the plain reference frame — records + frame kernel, nothing else on the stream — as one graph launch
     const bool as_graph = ctx->frame_graph_mode != 0u && !(rp.spp != 1 || rp.max_bounces != 0) && !aux && ctx->n_triangles == 0 &&
                           !(rp.flags & (RWR_FLAG_ORTHO_RAYS | RWR_FLAG_USE_BVH | RWR_FLAG_NO_CULL | RWR_FLAG_ONE_PIXEL_PER_LANE)) &&
@@ -977,7 +987,7 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
             // walks the whole scene instead — the same pixels — while the buffer grows for the next one.
             const size_t n_bins = (size_t)bins_x * bins_y;
             if (!sl.h_bin_total) {
-                RWR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&sl.h_bin_total), sizeof(uint32_t), hipHostMallocDefault));
+                RWR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&sl.h_bin_total), sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));   // fine-grained: kernels store to it, the host reads it without a synchronisation
                 *sl.h_bin_total = 0u;
             }
             const uint64_t needed = *sl.h_bin_total;
@@ -990,8 +1000,8 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
             RWR_HIP_CHECK(sl.d_bin_offsets.ensure(n_bins));
             RWR_HIP_CHECK(sl.d_bin_total.ensure(1));
             RWR_HIP_CHECK(launch_bin_faces(stream, sl.d_ftris.ptr, ctx->n_tris, row_begin, sl.d_bin_lists.ptr, sl.d_bin_counts.ptr,
-                                           sl.d_bin_offsets.ptr, sl.d_bin_total.ptr, bins_x, bins_y, (uint32_t)sl.d_bin_lists.count, fp.mesh_px));
-            RWR_HIP_CHECK(hipMemcpyAsync(sl.h_bin_total, sl.d_bin_total.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                                           sl.d_bin_offsets.ptr, sl.d_bin_total.ptr, bins_x, bins_y, (uint32_t)sl.d_bin_lists.count, fp.mesh_px,
+                                           sl.h_bin_total));   // (the scan writes the total to the pinned word itself: no copy command)
             fp.bins = BinGrid{sl.d_bin_lists.ptr, sl.d_bin_counts.ptr + 4u * (size_t)n_bins, sl.d_bin_offsets.ptr, bins_x, bins_y, (uint32_t)sl.d_bin_lists.count, 1u};
         }
     }
@@ -1040,8 +1050,7 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
         const uint32_t group = std::min(rp.spp, ctx->wf_group ? ctx->wf_group : (ctx->n_slots > 1u ? 64u : 32u));
         const uint32_t tiles_x = (ctx->screen.width + kWfTileW - 1u) / kWfTileW, tiles_y = band_strips(fp);
         const uint32_t n_tiles = tiles_x * tiles_y;
-        RWR_HIP_CHECK(W.d_wave_total.ensure((size_t)n_tiles * 4u));
-        RWR_HIP_CHECK(hipMemsetAsync(W.d_wave_total.ptr, 0, (size_t)n_tiles * 4u * sizeof(uint32_t), stream));
+        RWR_HIP_CHECK(W.d_wave_total.ensure((size_t)n_tiles * 4u));   // (sized and zeroed with the frame's records: k_frame_setup)
         if (W.d_fix.count < 4u * n) W.fix_clean = false;
         RWR_HIP_CHECK(W.d_fix.ensure(4u * n));
         if (!W.fix_clean)   // first use, a new size, or a frame that did not reach its resolve
@@ -1081,7 +1090,7 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
                 RWR_HIP_CHECK(hipMemsetAsync(W.d_live.ptr, 0, 4u * rwr_context::kWfMaxQueues * sizeof(uint32_t), stream));
             }
             if (!ctx->h_wf_live) {
-                RWR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_wf_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
+                RWR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_wf_live), 2 * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));   // fine-grained: kernels store to it, the host reads it without a synchronisation
                 ctx->h_wf_live[0] = ctx->h_wf_live[1] = 0u;
             }
         }
@@ -1107,8 +1116,7 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
         uint32_t *live_list = nullptr, *live_count = nullptr, *tile_live = nullptr;
         if (z_split > 1u && (shows_little || ctx->wf_z_split != 0u) && !(rp.flags & RWR_FLAG_NO_CULL)) {   // (a forced split: the tests' way in)
             RWR_HIP_CHECK(W.d_tiles.ensure(2u * (size_t)n_tiles + 1u));
-            live_list = W.d_tiles.ptr; tile_live = live_list + n_tiles; live_count = tile_live + n_tiles;
-            RWR_HIP_CHECK(hipMemsetAsync(live_count, 0, sizeof(uint32_t), stream));
+            live_list = W.d_tiles.ptr; tile_live = live_list + n_tiles; live_count = tile_live + n_tiles;   // (zeroed by k_frame_setup)
             RWR_HIP_CHECK(launch_wf_classify(stream, fp, sl.d_ftris.ptr, tg, tiles_x, live_list, live_count, tile_live));
         }
         WfBuffers wfq[rwr_context::kWfMaxQueues];
@@ -1128,6 +1136,7 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
             RWR_HIP_CHECK(hipEventRecord(W.fork, stream));
             for (size_t q = 1; q < n_queues; q++) RWR_HIP_CHECK(hipStreamWaitEvent(W.streams[q], W.fork, 0));
         }
+        const uint32_t *last_counters = nullptr;
         for (uint32_t s0 = 0, g = 0; s0 < rp.spp; s0 += group, g++) {
             const uint32_t cnt = std::min(group, rp.spp - s0);
             const size_t q = g % n_queues;
@@ -1137,15 +1146,17 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
                 RWR_HIP_CHECK(launch_wf_bounce(gs, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh, tex0, wfq[q], n_tiles, cnt,
                                                (uint32_t)std::fmax(1.0f, std::ceil(ctx->wf_packet_fill * (float)(cnt * kWfTilePixels))),
                                                W.d_pool_info.ptr + q * n_tiles * wf_pool_info_bytes(), W.d_pool_list.ptr + q * 2u * (size_t)n_tiles));
-                if (s0 + group >= rp.spp)   // the last group's live-pool counts, for the next frame's split
-                    RWR_HIP_CHECK(hipMemcpyAsync(ctx->h_wf_live, wfq[q].counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, gs));
+                if (s0 + group >= rp.spp) last_counters = wfq[q].counters;   // the last group's live-pool counts, for the next frame's split
             }
         }
         for (size_t q = 1; q < n_queues; q++) {
             RWR_HIP_CHECK(hipEventRecord(W.join[q], W.streams[q]));
             RWR_HIP_CHECK(hipStreamWaitEvent(stream, W.join[q], 0));
         }
-        RWR_HIP_CHECK(launch_wf_resolve(stream, fp, tg, wfq[0]));
+        // (the resolve also hands the last group's live pool counts to the host: a store to pinned memory, no copy command.  The
+        // same store at the top of the per-lane trace kernel made THAT kernel twice as slow, 453 -> 840 us at configs[3], with the
+        // pointer null and the instruction mix unchanged; here it costs nothing measurable.)
+        RWR_HIP_CHECK(launch_wf_resolve(stream, fp, tg, wfq[0], last_counters, last_counters ? ctx->h_wf_live : nullptr));
         W.fix_clean = true;   // (the resolve zeroes what it reads; rows outside the band were never touched)
         ctx->last_spp = rp.spp;
         ctx->last_segments = n_tiles;

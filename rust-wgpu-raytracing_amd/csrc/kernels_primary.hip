@@ -146,6 +146,11 @@ k_frame_setup(const CullConsts cc, const rwr_camera_inv_uniform cam, uint32_t wi
               const CullRec *__restrict__ cull, const TriRecord *__restrict__ tris, uint32_t n_tris, uint32_t nb_tris,
               const FrameSetupOut out)
 {
+    {   // what the frame wants zeroed: all workgroups together
+        const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+        for (uint32_t i = t; i < out.n_zero_a; i += stride) out.zero_a[i] = 0u;
+        for (uint32_t i = t; i < out.n_zero_b; i += stride) out.zero_b[i] = 0u;
+    }
     if (blockIdx.x >= nb_tris) {
         const uint32_t e = (blockIdx.x - nb_tris) * blockDim.x + threadIdx.x;
         const float(&p)[4][4] = cam.proj_inv;
@@ -249,7 +254,7 @@ k_bin_faces(const FrameTri *__restrict__ ftris, uint32_t n_tris, uint32_t row_be
 // kBinNoList when it exceeds capacity.
 __global__ void __launch_bounds__(1024)
 k_bin_scan(const uint32_t *__restrict__ counts4, uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets,
-           uint32_t *__restrict__ total_out, uint32_t n_bins, uint32_t capacity)
+           uint32_t *__restrict__ total_out, uint32_t *__restrict__ total_host, uint32_t n_bins, uint32_t capacity)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
@@ -280,21 +285,24 @@ k_bin_scan(const uint32_t *__restrict__ counts4, uint32_t *__restrict__ counts, 
         __syncthreads();
     }
     const uint32_t total = s_carry;
-    if (tid == 0) *total_out = total;
+    if (tid == 0) {
+        *total_out = total;
+        if (total_host) *total_host = total;   // pinned host memory: the context reads it a frame late, never waits for it
+    }
     if (total > capacity)   // uniform
         for (uint32_t b = tid; b < n_bins; b += 1024u) offsets[b] = kBinNoList;
 }
 
 hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *lists,
                             uint32_t *counts, uint32_t *offsets, uint32_t *total_out, uint32_t bins_x, uint32_t bins_y, uint32_t capacity,
-                            const int32_t mesh_px[4])
+                            const int32_t mesh_px[4], uint32_t *total_host)
 {
     if (n_tris == 0 || bins_x == 0 || bins_y == 0) return hipSuccess;
     uint32_t *counts4 = counts;                      // the counts buffer: four per bin (one per wave, 16-byte groups) ...
     counts += 4u * (size_t)bins_x * bins_y;          // ... then the bins' own counts, which the render kernels read
     hipLaunchKernelGGL((k_bin_faces<false>), dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts4, offsets, bins_x,
                        mesh_px[0], mesh_px[1], mesh_px[2], mesh_px[3]);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, counts4, counts, offsets, total_out, bins_x * bins_y, capacity);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, counts4, counts, offsets, total_out, total_host, bins_x * bins_y, capacity);
     hipLaunchKernelGGL((k_bin_faces<true>), dim3(bins_x, bins_y), dim3(256), 0, s, ftris, n_tris, row_begin, lists, counts4, offsets, bins_x,
                        mesh_px[0], mesh_px[1], mesh_px[2], mesh_px[3]);
     return hipGetLastError();

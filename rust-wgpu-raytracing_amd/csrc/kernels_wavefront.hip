@@ -96,8 +96,11 @@ hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRec
 
 template <bool AUX>
 __global__ void __launch_bounds__(256)
-k_wf_resolve(const FrameParams p, const Targets tg, WfBuffers wf)
+k_wf_resolve(const FrameParams p, const Targets tg, WfBuffers wf, const uint32_t *__restrict__ live_counters, uint32_t *__restrict__ host_live)
 {
+    // the last launch group's live pool counts {packets, per-lane} for the host (it sizes the NEXT frame's schedule by them, reads
+    // them a frame late and never waits): stored straight to pinned memory here instead of by a copy command on the stream
+    if (host_live && (blockIdx.x | blockIdx.y) == 0u && threadIdx.x < 2u) host_live[threadIdx.x] = live_counters[threadIdx.x];
     // a workgroup = 64 x 4 pixels (half a tile of the band's strip blockIdx.y / 2): one row of 64 per wave, whole 512-byte pieces
     // of every plane
     const uint32_t strip = blockIdx.y >> 1, in_strip = (blockIdx.y & 1u) * 4u + (threadIdx.x >> 6);
@@ -124,12 +127,13 @@ k_wf_resolve(const FrameParams p, const Targets tg, WfBuffers wf)
     if (AUX) reinterpret_cast<float4 *>(tg.color_f32)[pixel] = make_float4(r, g, b, a);
 }
 
-hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf)
+hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf, const uint32_t *live_counters,
+                             uint32_t *host_live)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
     const dim3 grid((fp.width + 63u) / 64u, 2u * band_strips(fp));
-    if (fp.flags & RWR_FLAG_AUX_OUTPUTS) hipLaunchKernelGGL((k_wf_resolve<true>), grid, dim3(256), 0, s, fp, tg, wf);
-    else hipLaunchKernelGGL((k_wf_resolve<false>), grid, dim3(256), 0, s, fp, tg, wf);
+    if (fp.flags & RWR_FLAG_AUX_OUTPUTS) hipLaunchKernelGGL((k_wf_resolve<true>), grid, dim3(256), 0, s, fp, tg, wf, live_counters, host_live);
+    else hipLaunchKernelGGL((k_wf_resolve<false>), grid, dim3(256), 0, s, fp, tg, wf, live_counters, host_live);
     return hipGetLastError();
 }
 

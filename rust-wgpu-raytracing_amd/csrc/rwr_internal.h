@@ -263,7 +263,9 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
 size_t wf_pool_info_bytes();
 hipError_t launch_primary_bvh(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                               const BvhDevice &bvh, const float4 *tex, const Targets &tg);
-hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf);
+// live_counters / host_live: the last launch group's counters (kernels_wf_bounce.hip) and the pinned words the host reads them from
+hipError_t launch_wf_resolve(hipStream_t s, const FrameParams &fp, const Targets &tg, const WfBuffers &wf, const uint32_t *live_counters = nullptr,
+                             uint32_t *host_live = nullptr);
 
 // per-frame records and tables (kernels_primary.hip): FrameTri + tnum per face, ray tables per column pair / row
 struct FrameSetupOut {
@@ -272,6 +274,10 @@ struct FrameSetupOut {
     float4 *ray_colp;  // 2 * ray_pairs
     float4 *ray_row;   // ray_rows
     uint32_t ray_pairs, ray_rows;
+    // words the frame wants zeroed before its first kernel (the wavefront integrator's per-tile ray counts and live-tile count):
+    // done here instead of by memset commands of their own on the stream (4-5 us each on a frame of a few hundred)
+    uint32_t *zero_a, *zero_b;
+    uint32_t n_zero_a, n_zero_b;
 };
 // kernels_dormant.hip: frames with single-triangle passes or orthographic rays (brute force, one pixel per lane)
 struct SingleTriangles {  // the single-triangle passes of a frame (kept out of FrameParams: only this kernel reads them)
@@ -312,7 +318,7 @@ hipError_t launch_frame_setup(hipStream_t s, const CullConsts &cc, const rwr_cam
 // count -> scan -> fill; *total_out (device) receives the entries the frame's lists need
 hipError_t launch_bin_faces(hipStream_t s, const FrameTri *ftris, uint32_t n_tris, uint32_t row_begin, uint32_t *lists,
                             uint32_t *counts, uint32_t *offsets, uint32_t *total_out, uint32_t bins_x, uint32_t bins_y, uint32_t capacity,
-                            const int32_t mesh_px[4]);
+                            const int32_t mesh_px[4], uint32_t *total_host);
 hipError_t launch_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                           const FrameTri *ftris, const float4 *tex, const Targets &tg);
 
