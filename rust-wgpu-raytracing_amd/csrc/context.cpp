@@ -132,7 +132,7 @@ struct rwr_context {
     float bvh_leaf_extent = 0.0f;
     float wf_packet_extent = 0.5f;   // x mean leaf extent; tunable: RWR_WF_PACKET_EXTENT
     uint32_t wf_min_packet_pools = 128;   // tunable: RWR_WF_MIN_PACKET_POOLS
-    uint32_t wf_lane_items = 16384;       // tunable: RWR_WF_LANE_ITEMS
+    uint32_t wf_lane_items = 0;           // tunable: RWR_WF_LANE_ITEMS (0: chosen per frame, see the BvhDevice of the wavefront path)
     float aabb_lo[3] = {0, 0, 0}, aabb_hi[3] = {0, 0, 0};   // of the (flattened) world-space faces
     float auto_bvh_face_px = 150.0f;   // tunable: RWR_AUTO_BVH_FACE_PX (0 = never pick the BVH kernel by itself)
     // wavefront integrator: tunables and what the host remembers of the last frame
@@ -1131,7 +1131,13 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
                                rp.max_bounces ? W.d_live.ptr + h * 4u : nullptr, overlap ? 1u : 0u, live_list, live_count, tile_live};
         }
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u,
-                            ctx->wf_packet_extent * ctx->bvh_leaf_extent, ctx->wf_min_packet_pools, ctx->wf_lane_items};
+                            ctx->wf_packet_extent * ctx->bvh_leaf_extent, ctx->wf_min_packet_pools,
+                            // work items of the per-lane trace kernel when pools are few: one 256-ray chunk each for a context that
+                            // renders one frame at a time (the chip has nothing else to do: as many items as possible), about four
+                            // chunks each when frames overlap (a pool's rays grow with the group's samples; measured at configs[3],
+                            // 16 samples: 0.625 -> 0.607 ms with 4 096 items, but 0.74 -> 0.79 ms one frame at a time; configs[4]'s
+                            // frame, 64 samples: 16 384 is best either way)
+                            ctx->wf_lane_items ? ctx->wf_lane_items : (ctx->n_slots > 1u ? std::min(16384u, 256u * group) : 16384u)};
         if (overlap) {   // the other streams start behind this frame's setup (and so behind the previous frame's resolve)
             RWR_HIP_CHECK(hipEventRecord(W.fork, stream));
             for (size_t q = 1; q < n_queues; q++) RWR_HIP_CHECK(hipStreamWaitEvent(W.streams[q], W.fork, 0));
