@@ -102,3 +102,27 @@ def test_auto_bvh_for_small_projected_faces_is_invisible(rwr, orc, gpu_ctx, cube
                             rwr.make_spheres(rwr.REFERENCE_SPHERES).view(orc.SPHERE_DTYPE), cube)
     assert np.array_equal(frames[0]["obj_id"], want["obj_id"]) and (frames[0]["obj_id"] >= 0).any()
     assert np.array_equal(frames[0]["depth"].view(np.uint32), want["depth"].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_frame_graph_knob_gives_the_same_frames(rwr, suzanne, monkeypatch):
+    """RWR_FRAME_GRAPH=1 (A/B knob, DESIGN §4.1: the reference frame's two launches as one hipGraph per slot, replayed while
+    the camera stands still and updated in place when it moves) changes how a frame is launched, never its bytes."""
+    w, h = 320, 180
+    cams = [rwr.camera_build_inv_uniform(rwr.make_camera(eye=(0.05 * k, 0.0, 3.0 - 0.1 * k), aspect=w / h)) for k in range(4)]
+    frames = {}
+    for graph in ("0", "1"):
+        monkeypatch.setenv("RWR_FRAME_GRAPH", graph)
+        with rwr.Context(0) as ctx:
+            ctx.upload_model(suzanne)
+            ctx.set_spheres(rwr.make_spheres())
+            ctx.resize(w, h)
+            ctx.set_frames_in_flight(2)
+            got = []
+            for cam in cams + cams[:2] + [cams[1]] * 3:      # moving, then standing still (replay), across both slots
+                ctx.render(cam, rwr.make_params())
+                out = ctx.readback()
+                got.append((out["color"].copy(), out["depth"].copy()))
+            frames[graph] = got
+    for (c0, d0), (c1, d1) in zip(frames["0"], frames["1"]):
+        assert np.array_equal(c0, c1) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32))
