@@ -344,6 +344,42 @@ int main(int argc, char **argv)
                    S, nb * nb, (double)c / nr, (double)pk_n / pk_w, (double)pk_f / pk_w, (double)pk_cost / nr);
         }
     }
+    // policy Q: pool = tile x S samples as in policy S, sort key = direction bin combined with the QUADRANT of the tile the ray
+    // starts in (32x4 pixels: the wave that emitted it) — origin-major, direction-major, or direction alone
+    if (S > 1) {
+        const int tw = 64, th = 8;
+        for (int mode = 0; mode < 3; mode++) for (int nb : {8, 16}) {
+            long c = 0; size_t nr = 0;
+            for (int by = 0; by < rows; by += th)
+                for (int bx = 0; bx < w; bx += tw) {
+                    struct E { int key; RayTrace r; };
+                    std::vector<E> pool;
+                    for (int sidx = 0; sidx < S; sidx++)
+                        for (int y = by; y < std::min(rows, by + th); y++)
+                            for (int x = bx; x < std::min(w, bx + tw); x++) {
+                                const size_t i = (size_t)y * w + x;
+                                if (!hit[i]) continue;
+                                const float *R = &rays[((size_t)sidx * rows * w + i) * 6];
+                                const float *D = R + 3;
+                                const int o = (D[0] < 0) | ((D[1] < 0) << 1) | ((D[2] < 0) << 2);
+                                const float l1 = std::fabs(D[0]) + std::fabs(D[1]) + std::fabs(D[2]);
+                                const int iu = std::min(nb - 1, (int)(std::fabs(D[0]) / l1 * nb)), iv = std::min(nb - 1, (int)(std::fabs(D[1]) / l1 * nb));
+                                const int dir = (o * nb + iv) * nb + iu, quad = ((x - bx) / 32) + 2 * ((y - by) / 4);
+                                const int key = mode == 0 ? dir : mode == 1 ? quad * 8 * nb * nb + dir : dir * 4 + quad;
+                                pool.push_back({key, trace(bvh, R, D)});
+                            }
+                    std::stable_sort(pool.begin(), pool.end(), [](const E &a, const E &b) { return a.key < b.key; });
+                    nr += pool.size();
+                    for (size_t base = 0; base < pool.size(); base += 64) {
+                        std::vector<Lane> L(64);
+                        for (int lane = 0; lane < 64 && base + lane < pool.size(); lane++) L[lane].r = &pool[base + lane].r;
+                        c += run_wave_static(L) + 40;
+                    }
+                }
+            printf("per-lane, 64x8 tile pools, key %s, %2dx%2d cells per octant: %8.1f wave-instr per ray\n",
+                   mode == 0 ? "direction          " : mode == 1 ? "quadrant, direction" : "direction, quadrant", nb, nb, (double)c / nr);
+        }
+    }
     // policy D: ray STREAM traversal — per pool (tile x S samples), octant and BATCH of B direction-sorted rays, every BVH node / leaf
     // face is visited ONCE with the list of the batch's rays that reach it (wave-uniform node, rays 64 at a time, compaction into
     // the children's lists); priced per chunk of 64 rays: node 80, face 100 wave instructions (+ list upkeep); rays visit what they
