@@ -91,10 +91,16 @@ struct FrameSlot {
     // hipGraph of this slot — replayed as it is while camera and parameters stay the same, updated in place when they change
     hipGraphExec_t frame_graph = nullptr;
     std::vector<unsigned char> frame_graph_key;
+    // the frame kernel's fused form (one launch per frame): {finished record blocks, "a wait ran out"} on the device, the count
+    // the host expects before the next frame, and the block count it is valid for
+    DeviceBuffer<uint32_t> d_fused;
+    uint32_t fused_count = 0, fused_blocks = 0;
+    bool fused_used = false;
     void release_buffers()
     {
         if (frame_graph) { (void)hipGraphExecDestroy(frame_graph); frame_graph = nullptr; }
         frame_graph_key.clear();
+        d_fused.release(); fused_count = 0; fused_blocks = 0; fused_used = false;
         d_color.release(); d_depth.release(); d_color_f32.release(); d_obj_id.release(); d_hit_t.release();
         d_ftris.release(); d_tnum.release(); d_ray_colp.release(); d_ray_row.release();
         d_bin_lists.release(); d_bin_counts.release(); d_bin_offsets.release(); d_bin_total.release();
@@ -125,6 +131,8 @@ struct rwr_context {
     uint32_t bin_min_capacity = 65536;                  // tunable: RWR_BIN_CAPACITY (entries the bin lists start with)
     bool force_one_pixel = false;                       // debug: RWR_ONE_PIXEL_PER_LANE=1
     uint32_t frame_graph_mode = 0;                      // A/B: RWR_FRAME_GRAPH=1 (hipGraph replay / update of the reference frame's launches)
+    bool fused_setup = true;                            // one launch per small reference frame (k_primary_p2<FUSED>); RWR_FUSED_SETUP=0: two
+    bool fused_setup_force = false;                     // RWR_FUSED_SETUP=1: wherever the fused form is possible
     // BVH over the (flattened) world-space faces, for bounce rays
     DeviceBuffer<BvhNode4> d_bvh_nodes;
     DeviceBuffer<uint32_t> d_bvh_leaf_faces;
@@ -534,6 +542,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     if (const char *e2 = std::getenv("RWR_WAVE_CULL_MIN")) ctx->wave_cull_min = (uint32_t)std::strtoul(e2, nullptr, 10);
     if (const char *e4 = std::getenv("RWR_ONE_PIXEL_PER_LANE")) ctx->force_one_pixel = std::atoi(e4) != 0;
     if (const char *e14 = std::getenv("RWR_FRAME_GRAPH")) ctx->frame_graph_mode = (uint32_t)std::atoi(e14);
+    if (const char *e16 = std::getenv("RWR_FUSED_SETUP")) { ctx->fused_setup = std::atoi(e16) != 0; ctx->fused_setup_force = ctx->fused_setup; }
     if (const char *e5 = std::getenv("RWR_AUTO_BVH_FACE_PX")) ctx->auto_bvh_face_px = (float)std::atof(e5);
     if (const char *e6 = std::getenv("RWR_WF_GROUP")) ctx->wf_group = std::min(kWfMaxGroup, std::max(1u, (uint32_t)std::strtoul(e6, nullptr, 10)));
     if (const char *e9 = std::getenv("RWR_WF_STATS")) {
@@ -976,6 +985,47 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
         ctx->last_bounce = 0;
         return RWR_OK;
     }
+    // The plain reference frame — records + frame kernel, nothing else — as ONE launch: the frame kernel's first workgroups
+    // make the records (kernels_primary_p2.hip, FUSED).
+    // Where it pays (A/B in one box, tools/fused_ab.py, profiles/r03_fused_ab.txt): SMALL frames with frames in flight, which
+    // are bound by the host's launches — one rank's share of a multi-GPU 1080p frame: 9.8 -> 6.9 us per frame (1/8), 10.4 -> 8.2
+    // (1/4), the host's enqueue time 9.8 -> 5.2 us.  A whole 1080p frame is VALU-bound and LOSES (15.0 -> 17.4 us with two slots:
+    // the next frame's waiting workgroups hold slots the running frame could use; 22.7 -> 23.8 us alone), so it keeps its two
+    // launches.  RWR_FUSED_SETUP=1 forces the fused form wherever it is possible (tests), 0 switches it off.
+    const uint32_t render_groups = ((ctx->screen.width + 63u) / 64u) * ((row_end - row_begin + row_pitch - 1u) / std::max(1u, row_pitch));
+    const bool fused_pays = ctx->fused_setup_force || (ctx->n_slots > 1u && render_groups <= 1200u);
+    const bool fused = ctx->fused_setup && fused_pays && !(rp.spp != 1 || rp.max_bounces != 0) && !aux && ctx->n_triangles == 0 &&
+                       !(rp.flags & (RWR_FLAG_ORTHO_RAYS | RWR_FLAG_USE_BVH | RWR_FLAG_NO_CULL | RWR_FLAG_ONE_PIXEL_PER_LANE | RWR_FLAG_NORMAL_MAP)) &&
+                       !ctx->force_one_pixel && ctx->n_tris != 0 && ctx->n_tris <= ctx->bin_min_faces && !ctx->timing_every &&
+                       row_end > row_begin;
+    if (fused) {
+        FusedSetup fs{};
+        fs.cc = cc;
+        fs.cull = ctx->d_cull.ptr;
+        fs.out = so;
+        fs.nb_tris = (ctx->n_tris + 255u) / 256u;
+        fs.n_blocks = fs.nb_tris + (so.ray_pairs + so.ray_rows + 255u) / 256u;
+        fs.extra_rows = primary_p2_fused_rows(fp, fs.n_blocks);
+        if (!sl.d_fused.ptr || sl.fused_blocks != fs.n_blocks) {   // first use, or another scene / frame size: the count starts over
+            RWR_HIP_CHECK(hipStreamSynchronize(stream));
+            RWR_HIP_CHECK(sl.d_fused.ensure(2));
+            RWR_HIP_CHECK(hipMemsetAsync(sl.d_fused.ptr, 0, 2 * sizeof(uint32_t), stream));
+            sl.fused_count = 0;
+            sl.fused_blocks = fs.n_blocks;
+        }
+        fs.flag = sl.d_fused.ptr;
+        fs.flag_base = sl.fused_count;
+        sl.fused_count += fs.n_blocks;   // (modulo 2^32, like the device's count)
+        sl.fused_used = true;
+        RWR_HIP_CHECK(launch_primary_p2(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, sl.d_ftris.ptr, tex0, tg, nullptr, nullptr, &fs));
+        sl.aux_valid = false;
+        ctx->last_spp = 0;
+        ctx->last_had_bounce = false;
+        ctx->last_primary = 0;
+        for (uint32_t y0 = row_begin; y0 < row_end; y0 += row_pitch) ctx->last_primary += (uint64_t)std::min(kStripRows, row_end - y0) * ctx->screen.width;
+        ctx->last_bounce = 0;
+        return RWR_OK;
+    }
     RWR_HIP_CHECK(launch_frame_setup(stream, cc, *camera, ctx->screen.width, ctx->screen.height, ctx->d_cull.ptr,
                                      ctx->d_tris.ptr, ctx->n_tris, so));
     if (ctx->n_tris && !(rp.flags & RWR_FLAG_NO_CULL)) {
@@ -1203,11 +1253,31 @@ int rwr_render_strips(rwr_context *ctx, const rwr_camera_inv_uniform *camera, co
     return render_frame(ctx, camera, params, std::min(first_row, h), h, strip_stride * kStripRows);
 }
 
+// A frame rendered by the fused frame kernel is complete unless one of its waves waited in vain for the records (the wait is
+// bounded; it has never been seen to run out): slot `i` is idle when this is called.
+static int check_fused_frame(rwr_context *ctx, uint32_t i)
+{
+    FrameSlot &sl = ctx->slots[i];
+    if (!sl.fused_used || !sl.d_fused.ptr) return RWR_OK;
+    uint32_t timed_out = 0;
+    RWR_HIP_CHECK(hipMemcpy(&timed_out, sl.d_fused.ptr + 1, sizeof timed_out, hipMemcpyDeviceToHost));
+    if (timed_out) {
+        sl.fused_blocks = 0;   // the count is no longer what the host expects: start over with the next frame
+        return set_error(RWR_ERR_HIP, "a frame is incomplete: workgroups of the fused frame kernel waited in vain for the frame's records "
+                         "(RWR_FUSED_SETUP=0 renders with two launches per frame)");
+    }
+    return RWR_OK;
+}
+
 int rwr_synchronize(rwr_context *ctx)
 {
     if (!ctx) return set_error(RWR_ERR_INVALID_ARGUMENT, "ctx is NULL");
     DeviceGuard g(ctx->device);
     RWR_HIP_CHECK(sync_all(ctx));
+    for (uint32_t i = 0; i < ctx->n_slots; i++) {
+        const int rc = check_fused_frame(ctx, i);
+        if (rc != RWR_OK) return rc;
+    }
     return RWR_OK;
 }
 
@@ -1220,6 +1290,10 @@ int rwr_readback(rwr_context *ctx, uint8_t *rgba8, float *depth, float *rgba_f32
     DeviceGuard g(ctx->device);
     const size_t n = (size_t)ctx->screen.width * ctx->screen.height;
     RWR_HIP_CHECK(hipStreamSynchronize(ctx->slots[ctx->cur].stream));
+    {
+        const int rc = check_fused_frame(ctx, ctx->cur);
+        if (rc != RWR_OK) return rc;
+    }
     if (rgba8) RWR_HIP_CHECK(hipMemcpy(rgba8, ctx->slots[ctx->cur].d_color.ptr, n * 4, hipMemcpyDeviceToHost));
     if (depth) RWR_HIP_CHECK(hipMemcpy(depth, ctx->slots[ctx->cur].d_depth.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
     if (rgba_f32) RWR_HIP_CHECK(hipMemcpy(rgba_f32, ctx->slots[ctx->cur].d_color_f32.ptr, n * 4 * sizeof(float), hipMemcpyDeviceToHost));

@@ -9,6 +9,7 @@
 //   the face record in scalar registers.  No LDS, no barrier.
 #include <hip/hip_ext.h>
 
+#include "rwr_frame_setup.h"
 #include "rwr_primary.h"
 #include "rwr_shade_p2.h"
 
@@ -25,7 +26,13 @@ namespace rwr {
 #endif
 // NMAP: normal-mapped shading (extension, RWR_FLAG_NORMAL_MAP) — its own instantiation, so that the reference's frame keeps
 // its registers.
-template <bool AUX, bool CULL, bool NMAP>
+// FUSED: ONE launch per frame (the reference submits a frame once, lib.rs:1226).  The grid's first rows are workgroups that
+// make the frame's records and tables — the work of k_frame_setup, rwr_frame_setup.h — and count themselves off in
+// FusedSetup::flag; every other workgroup waits for that count before it touches a record (workgroups are dispatched in
+// order of their flattened index, so the record makers are running before a waiting one exists; the wait is BOUNDED all the
+// same: a wave whose wait runs out flags the frame as incomplete and leaves, it never hangs).  Saves the host one of its two
+// launches per frame and the device the boundary between them.
+template <bool AUX, bool CULL, bool NMAP, bool FUSED = false>
 __global__ void __launch_bounds__(256, (AUX || NMAP) ? 4 : RWR_P2_OCC)
 // (the first eleven arguments repeat FrameParams fields: they are what a wave needs first, and the Makefile
 // has their 14 dwords preloaded into SGPRs)
@@ -33,18 +40,62 @@ k_primary_p2(const FrameTri *__restrict__ ftris, const float4 *__restrict__ ray_
              uint32_t n_tris, uint32_t row_begin, uint32_t bins_enabled, uint32_t row_pitch,
              int32_t mesh_x0, int32_t mesh_y0, int32_t mesh_x1, int32_t mesh_y1,
              const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
-             const float4 *__restrict__ tex, const Targets tg)
+             const float4 *__restrict__ tex, const Targets tg, const FusedSetup fs)
 {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t by = blockIdx.y;
+    const_ptr<TriRecord> tris_c = nullptr;
+    const_ptr<ShadeRec> shade_c = nullptr;
+    const_ptr<float> tnum_c = nullptr;
+    if (FUSED) {
+        if (blockIdx.y < fs.extra_rows) {   // a record-making workgroup (or a spare one of the last extra row)
+            const uint32_t f = blockIdx.y * gridDim.x + blockIdx.x;
+            if (f < fs.n_blocks) {
+                frame_setup_block(f, fs.n_blocks, fs.cc, p.cam, p.width, p.height, fs.cull, tris, n_tris, fs.nb_tris, fs.out);
+                __threadfence();      // the records are visible to the device ...
+                __syncthreads();
+                if (threadIdx.x == 0u) atomicAdd(fs.flag, 1u);   // ... before the block counts itself off
+            }
+            return;
+        }
+        by -= fs.extra_rows;
+        // One wave per workgroup watches the count (thousands of waves polling one word swamp its L2 channel: measured, a
+        // frame took 125 us), the others wait for it at a barrier.
+        __shared__ uint32_t s_ready;
+        if (wave == 0u) {
+            uint32_t spins = 0;
+            bool ok = true;
+            while (__hip_atomic_load(fs.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fs.flag_base < fs.n_blocks) {   // (wave-uniform)
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1u << 15)) { ok = false; break; }   // ~15 ms: never in practice — and never a hang
+            }
+            if (lane == 0u) {
+                s_ready = ok ? 1u : 0u;
+                if (!ok) atomicOr(fs.flag + 1, 1u);
+            }
+        }
+        __syncthreads();
+        if (s_ready == 0u) return;   // the frame is flagged incomplete (rwr_synchronize / rwr_readback report it)
+        // No cache invalidation here on purpose: the kernel's launch invalidated this CU's caches, and no wave reads a line of
+        // the records before this point (they are allocations of their own), so no stale line can be resident; what is needed
+        // is that the loads below are ISSUED after the count was seen, which the pointers re-made here guarantee.
+        // everything the record makers wrote is read through pointers made HERE, behind the wait
+        asm volatile("" : "+s"(ftris), "+s"(ray_colp), "+s"(ray_row));
+        const float *tn = p.tnum;
+        asm volatile("" : "+s"(tn));
+        tnum_c = to_const_space(tn);
+        tris_c = to_const_space(tris);
+        shade_c = to_const_space(shade);
+    }
     const uint32_t blk_x0 = blockIdx.x * 64u;
 #if RWR_P2_TILE_32x4
     const uint32_t tile_x0 = blk_x0 + (wave & 1u) * 32u;
-    const uint32_t tile_y0 = row_begin + blockIdx.y * row_pitch + (wave >> 1) * 4u;
+    const uint32_t tile_y0 = row_begin + by * row_pitch + (wave >> 1) * 4u;
     const uint32_t px0 = tile_x0 + 2u * (lane & 15u), py = tile_y0 + (lane >> 4);
     constexpr float kTileWf = 32.0f, kTileHf = 4.0f;
 #else
     const uint32_t tile_x0 = blk_x0 + wave * 16u;
-    const uint32_t tile_y0 = p.row_begin + blockIdx.y * row_pitch;
+    const uint32_t tile_y0 = p.row_begin + by * row_pitch;
     const uint32_t px0 = tile_x0 + 2u * (lane & 7u), py = tile_y0 + (lane >> 3);
     constexpr float kTileWf = 16.0f, kTileHf = 8.0f;
 #endif
@@ -65,10 +116,10 @@ k_primary_p2(const FrameTri *__restrict__ ftris, const float4 *__restrict__ ray_
     if (CULL) {  // the tile lies outside the screen rectangle of the whole mesh: scalar integer compares
         const int32_t wu = __builtin_amdgcn_readfirstlane((int32_t)wave);
 #if RWR_P2_TILE_32x4
-        const int32_t sx0 = (int32_t)blk_x0 + (wu & 1) * 32, sy0 = (int32_t)(row_begin + blockIdx.y * row_pitch) + (wu >> 1) * 4;
+        const int32_t sx0 = (int32_t)blk_x0 + (wu & 1) * 32, sy0 = (int32_t)(row_begin + by * row_pitch) + (wu >> 1) * 4;
         const int32_t sx1 = sx0 + 32, sy1 = sy0 + 4;
 #else
-        const int32_t sx0 = (int32_t)blk_x0 + wu * 16, sy0 = (int32_t)(row_begin + blockIdx.y * row_pitch);
+        const int32_t sx0 = (int32_t)blk_x0 + wu * 16, sy0 = (int32_t)(row_begin + by * row_pitch);
         const int32_t sx1 = sx0 + 16, sy1 = sy0 + 8;
 #endif
         if (sx1 < mesh_x0 || sx0 > mesh_x1 || sy1 < mesh_y0 || sy0 > mesh_y1) n_src = 0u;
@@ -131,9 +182,14 @@ k_primary_p2(const FrameTri *__restrict__ ftris, const float4 *__restrict__ ray_
                 m &= m - 1ull;
                 // wave-uniform face index: the record comes in through scalar loads
                 const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_face, (int)b);
-                intersect_and_select(tris[idx], p.tnum[idx], idx, O, D, best);
+                if (FUSED) {
+                    intersect_and_select(load_tri_record(tris_c + idx), tnum_c[idx], idx, O, D, best);
+                    last_shade = load_shade_record(shade_c + idx);
+                } else {
+                    intersect_and_select(tris[idx], p.tnum[idx], idx, O, D, best);
+                    last_shade = shade[idx];
+                }
                 n_tested++;
-                last_shade = shade[idx];
                 if (AUX) dbg_tested++;
             }
         }
@@ -225,30 +281,39 @@ k_primary_p2(const FrameTri *__restrict__ ftris, const float4 *__restrict__ ray_
     }
 }
 
+uint32_t primary_p2_fused_rows(const FrameParams &fp, uint32_t n_blocks)
+{
+    const uint32_t gx = (fp.width + 63u) / 64u;
+    return gx ? (n_blocks + gx - 1u) / gx : 0u;
+}
+
 hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                              const FrameTri *ftris, const float4 *tex, const Targets &tg, hipEvent_t ev_start,
-                             hipEvent_t ev_stop)
+                             hipEvent_t ev_stop, const FusedSetup *fused)
 {
     if (fp.row_end <= fp.row_begin || fp.width == 0) return hipSuccess;
-    const dim3 grid((fp.width + 63u) / 64u, band_strips(fp));
+    const dim3 grid((fp.width + 63u) / 64u, band_strips(fp) + (fused ? fused->extra_rows : 0u));
     const dim3 block(256);
     const bool aux = (fp.flags & RWR_FLAG_AUX_OUTPUTS) != 0;
     const bool do_cull = (fp.flags & RWR_FLAG_NO_CULL) == 0;
     // ev_start / ev_stop (may be null): timestamps of this dispatch itself (hipExtLaunchKernelGGL), i.e. the
     // kernel's own duration as a profiler reports it, without the gap to the preceding kernel
     const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0 && fp.tangents != nullptr;
-#define RWR_P2_LAUNCH(A, C, N) hipExtLaunchKernelGGL((k_primary_p2<A, C, N>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, \
-    fp.n_tris, fp.row_begin, fp.bins.enabled, fp.row_pitch, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg)
-    if (nmap) {
-        if (aux && do_cull) RWR_P2_LAUNCH(true, true, true);
-        else if (aux) RWR_P2_LAUNCH(true, false, true);
-        else if (do_cull) RWR_P2_LAUNCH(false, true, true);
-        else RWR_P2_LAUNCH(false, false, true);
+    const FusedSetup fs = fused ? *fused : FusedSetup{};
+#define RWR_P2_LAUNCH(A, C, N, F) hipExtLaunchKernelGGL((k_primary_p2<A, C, N, F>), grid, block, 0, s, ev_start, ev_stop, 0, ftris, fp.ray_colp, fp.ray_row, \
+    fp.n_tris, fp.row_begin, fp.bins.enabled, fp.row_pitch, fp.mesh_px[0], fp.mesh_px[1], fp.mesh_px[2], fp.mesh_px[3], fp, tris, shade, tex, tg, fs)
+    if (fused) {   // (the plain reference frame only: context.cpp)
+        RWR_P2_LAUNCH(false, true, false, true);
+    } else if (nmap) {
+        if (aux && do_cull) RWR_P2_LAUNCH(true, true, true, false);
+        else if (aux) RWR_P2_LAUNCH(true, false, true, false);
+        else if (do_cull) RWR_P2_LAUNCH(false, true, true, false);
+        else RWR_P2_LAUNCH(false, false, true, false);
     } else {
-        if (aux && do_cull) RWR_P2_LAUNCH(true, true, false);
-        else if (aux) RWR_P2_LAUNCH(true, false, false);
-        else if (do_cull) RWR_P2_LAUNCH(false, true, false);
-        else RWR_P2_LAUNCH(false, false, false);
+        if (aux && do_cull) RWR_P2_LAUNCH(true, true, false, false);
+        else if (aux) RWR_P2_LAUNCH(true, false, false, false);
+        else if (do_cull) RWR_P2_LAUNCH(false, true, false, false);
+        else RWR_P2_LAUNCH(false, false, false, false);
     }
 #undef RWR_P2_LAUNCH
     return hipGetLastError();

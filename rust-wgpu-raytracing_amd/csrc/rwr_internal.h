@@ -248,9 +248,12 @@ struct BvhDevice {
     uint32_t lane_items;        // work items the per-lane kernel's launch should have when pools are few (pool_split; tunable)
 };
 
+struct FusedSetup;
 hipError_t launch_primary_p2(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                              const FrameTri *ftris, const float4 *tex, const Targets &tg, hipEvent_t ev_start = nullptr,
-                             hipEvent_t ev_stop = nullptr);
+                             hipEvent_t ev_stop = nullptr, const FusedSetup *fused = nullptr);
+// grid rows the fused form puts in front of the frame's strips for `n_blocks` record-making workgroups
+uint32_t primary_p2_fused_rows(const FrameParams &fp, uint32_t n_blocks);
 hipError_t launch_wf_primary(hipStream_t s, const FrameParams &fp, const TriRecord *tris, const ShadeRec *shade,
                              const FrameTri *ftris, const float4 *tex, const Targets &tg,
                              const WfBuffers &wf, uint32_t sample_begin, uint32_t sample_count, uint32_t z_split);
@@ -279,6 +282,19 @@ struct FrameSetupOut {
     uint32_t *zero_a, *zero_b;
     uint32_t n_zero_a, n_zero_b;
 };
+// The frame kernel's FUSED form (one launch per frame, kernels_primary_p2.hip): the grid's first rows are workgroups that make
+// the frame's records and tables (the work of k_frame_setup), the others wait until all of them have finished.
+struct FusedSetup {
+    CullConsts cc;
+    const CullRec *cull;
+    FrameSetupOut out;
+    uint32_t n_blocks;     // record-making workgroups: blocks of k_frame_setup's grid
+    uint32_t nb_tris;      // ... of which make face records
+    uint32_t extra_rows;   // grid rows in front of the frame's own strips: ceil(n_blocks / grid.x)
+    uint32_t flag_base;    // flag[0] before this frame (it counts finished record blocks: + n_blocks per frame, modulo 2^32)
+    uint32_t *flag;        // [0] finished record blocks, [1] != 0: a wait ran out (the frame is incomplete; rwr_synchronize says so)
+};
+
 // kernels_dormant.hip: frames with single-triangle passes or orthographic rays (brute force, one pixel per lane)
 struct SingleTriangles {  // the single-triangle passes of a frame (kept out of FrameParams: only this kernel reads them)
     uint32_t n;

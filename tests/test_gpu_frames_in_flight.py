@@ -126,3 +126,37 @@ def test_frame_graph_knob_gives_the_same_frames(rwr, suzanne, monkeypatch):
             frames[graph] = got
     for (c0, d0), (c1, d1) in zip(frames["0"], frames["1"]):
         assert np.array_equal(c0, c1) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_one_launch_per_frame_gives_the_same_frames(rwr, orc, suzanne, monkeypatch, fused):
+    """The frame kernel's fused form (its first workgroups make the frame's records, the others wait for them: ONE launch per
+    frame, the default for small frames with frames in flight) against two launches (RWR_FUSED_SETUP=0) and against the oracle:
+    whole frames, strips of a multi-GPU frame, a moving camera, 1-3 frame slots."""
+    w, h = 328, 181
+    monkeypatch.setenv("RWR_FUSED_SETUP", fused)
+    cams = [rwr.camera_build_inv_uniform(rwr.make_camera(eye=(0.07 * k, 0.02 * k, 3.0 - 0.15 * k), aspect=w / h)) for k in range(5)]
+    want = orc.render_frame(cams[2].view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), orc.make_spheres(), suzanne)
+    with rwr.Context(0) as ctx:
+        ctx.upload_model(suzanne)
+        ctx.set_spheres(rwr.make_spheres())
+        ctx.resize(w, h)
+        for fif in (1, 2, 3):
+            ctx.set_frames_in_flight(fif)
+            for rep in range(3):
+                for k, cam in enumerate(cams):
+                    ctx.render(cam, rwr.make_params())
+                    if k == 2:
+                        got = ctx.readback()
+                        assert np.array_equal(got["depth"].view(np.uint32), want["depth"].view(np.uint32)), (fif, rep)
+                        assert np.abs(got["color"].astype(int) - want["color"].astype(int)).max() <= 1
+            full = ctx.readback()["color"]        # the frame of cams[4]
+            asm = np.zeros_like(full)
+            for r in range(3):                    # the same frame as three ranks' strips
+                ctx.render(cams[4], rwr.make_params(), strips=(r, 3))
+                part = ctx.readback()["color"]
+                rows = [y for s in range(r, (h + 7) // 8, 3) for y in range(8 * s, min(h, 8 * s + 8))]
+                asm[rows] = part[rows]
+            assert np.array_equal(asm, full), fif
+        ctx.synchronize()
