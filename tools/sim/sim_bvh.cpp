@@ -380,6 +380,64 @@ int main(int argc, char **argv)
                    mode == 0 ? "direction          " : mode == 1 ? "quadrant, direction" : "direction, quadrant", nb, nb, (double)c / nr);
         }
     }
+    // policy R: the direction-sorted tile pool (policy Q, direction key) walked by a PERSISTENT wave that refills idle lanes from
+    // the sorted list when at least T of them are idle; a refill event costs the fetch of the new rays AND the epilogue of the
+    // finished ones (shading + accumulation: 210), the static schedule pays 190 per 64 rays
+    if (S > 1) {
+        const int tw = 64, th = 8, nb = 16;
+        for (int thresh : {0, 8, 16, 24, 32, 48}) {
+            long c = 0; size_t nr = 0;
+            for (int by = 0; by < rows; by += th)
+                for (int bx = 0; bx < w; bx += tw) {
+                    struct E { int key; RayTrace r; };
+                    std::vector<E> pool;
+                    for (int sidx = 0; sidx < S; sidx++)
+                        for (int y = by; y < std::min(rows, by + th); y++)
+                            for (int x = bx; x < std::min(w, bx + tw); x++) {
+                                const size_t i = (size_t)y * w + x;
+                                if (!hit[i]) continue;
+                                const float *R = &rays[((size_t)sidx * rows * w + i) * 6];
+                                const float *D = R + 3;
+                                const int o = (D[0] < 0) | ((D[1] < 0) << 1) | ((D[2] < 0) << 2);
+                                const float l1 = std::fabs(D[0]) + std::fabs(D[1]) + std::fabs(D[2]);
+                                const int iu = std::min(nb - 1, (int)(std::fabs(D[0]) / l1 * nb)), iv = std::min(nb - 1, (int)(std::fabs(D[1]) / l1 * nb));
+                                pool.push_back({(o * nb + iv) * nb + iu, trace(bvh, R, D)});
+                            }
+                    std::stable_sort(pool.begin(), pool.end(), [](const E &a, const E &b) { return a.key < b.key; });
+                    nr += pool.size();
+                    if (thresh == 0) {   // static: 64 rays, all to the end
+                        for (size_t base = 0; base < pool.size(); base += 64) {
+                            std::vector<Lane> L(64);
+                            for (int lane = 0; lane < 64 && base + lane < pool.size(); lane++) L[lane].r = &pool[base + lane].r;
+                            c += run_wave_static(L) + 190;
+                        }
+                        continue;
+                    }
+                    std::vector<Lane> L(64);
+                    size_t next = 0;
+                    auto idle = [&] { int n = 0; for (auto &l : L) if (!l.active()) n++; return n; };
+                    for (;;) {
+                        if (next < pool.size() && idle() >= thresh) { for (auto &l : L) if (!l.active() && next < pool.size()) { l.r = &pool[next++].r; l.pc = 0; } c += 210; }
+                        bool any = false; for (auto &l : L) if (l.active()) any = true;
+                        if (!any) { if (next >= pool.size()) break; continue; }
+                        // one while-while round: inner steps until no lane sits on an inner node or enough lanes went idle, then leaves
+                        for (;;) {
+                            bool any_inner = false;
+                            for (auto &l : L) if (l.active() && l.r->steps[l.pc].kind == 0) { any_inner = true; l.pc++; }
+                            if (!any_inner) break;
+                            c += g_cost_inner;
+                            if (next < pool.size() && idle() >= thresh) break;
+                        }
+                        bool any_leaf = false;
+                        for (auto &l : L) if (l.active() && l.r->steps[l.pc].kind == 1) any_leaf = true;
+                        if (any_leaf) c += leaf_phase_cost(L);
+                    }
+                    c += 150;   // the last rays' epilogue
+                }
+            printf("sorted tile pools, per-lane, %s: %8.1f wave-instr per ray (with ray fetch and epilogue)\n",
+                   thresh == 0 ? "static 64 rays per wave     " : (std::string("refill at ") + std::to_string(thresh) + " idle lanes     ").c_str(), (double)c / nr);
+        }
+    }
     // policy D: ray STREAM traversal — per pool (tile x S samples), octant and BATCH of B direction-sorted rays, every BVH node / leaf
     // face is visited ONCE with the list of the batch's rays that reach it (wave-uniform node, rays 64 at a time, compaction into
     // the children's lists); priced per chunk of 64 rays: node 80, face 100 wave instructions (+ list upkeep); rays visit what they
