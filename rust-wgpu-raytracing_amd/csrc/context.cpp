@@ -141,6 +141,12 @@ struct rwr_context {
     float wf_packet_extent = 0.5f;   // x mean leaf extent; tunable: RWR_WF_PACKET_EXTENT
     uint32_t wf_min_packet_pools = 128;   // tunable: RWR_WF_MIN_PACKET_POOLS
     uint32_t wf_lane_items = 0;           // tunable: RWR_WF_LANE_ITEMS (0: chosen per frame, see the BvhDevice of the wavefront path)
+    uint32_t wf_packet_dense_rays = 16384;   // a pool of at least this many rays (32 samples of a full tile) is traced as packets
+                                             // however far apart its rays start; tunable: RWR_WF_PACKET_RAYS (0: never).  Measured
+                                             // (tools/packet_rays_sweep.sh): configs[4]'s frame, 64 samples per group, 2.11 -> 1.75
+                                             // ms with any threshold from 2 000 to 24 000 (2.30 -> 2.18 one frame at a time at
+                                             // 16 000); configs[3], 16 samples (pools of at most 8 192): 0.604 -> 0.71-0.77 ms
+                                             // with thresholds up to 8 000, unchanged from 12 000
     float aabb_lo[3] = {0, 0, 0}, aabb_hi[3] = {0, 0, 0};   // of the (flattened) world-space faces
     float auto_bvh_face_px = 150.0f;   // tunable: RWR_AUTO_BVH_FACE_PX (0 = never pick the BVH kernel by itself)
     // wavefront integrator: tunables and what the host remembers of the last frame
@@ -550,6 +556,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     }
     if (const char *e13 = std::getenv("RWR_WF_OVERLAP")) ctx->wf_queues = std::min(rwr_context::kWfMaxQueues, std::max(1u, (uint32_t)std::strtoul(e13, nullptr, 10)));
     if (const char *e12 = std::getenv("RWR_WF_ZSPLIT")) ctx->wf_z_split = (uint32_t)std::strtoul(e12, nullptr, 10);
+    if (const char *e19 = std::getenv("RWR_WF_PACKET_RAYS")) ctx->wf_packet_dense_rays = (uint32_t)std::strtoul(e19, nullptr, 10);
     if (const char *e15 = std::getenv("RWR_WF_LANE_ITEMS")) ctx->wf_lane_items = std::max(1u, (uint32_t)std::strtoul(e15, nullptr, 10));
     if (const char *e10 = std::getenv("RWR_WF_MIN_PACKET_POOLS")) ctx->wf_min_packet_pools = (uint32_t)std::strtoul(e10, nullptr, 10);
     if (const char *e8 = std::getenv("RWR_WF_PACKET_EXTENT")) ctx->wf_packet_extent = (float)std::atof(e8);
@@ -1081,7 +1088,7 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
         RWR_HIP_CHECK(launch_primary_dormant(stream, fp, st, ctx->d_tris.ptr, ctx->d_shade.ptr, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront && ((rp.flags & RWR_FLAG_USE_BVH) || auto_bvh)) {
-        const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u, 0.0f, 0u, 0u};
+        const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u, 0.0f, 0u, 0u, 0u};
         RWR_HIP_CHECK(launch_primary_bvh(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh_p, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront) {
@@ -1187,7 +1194,8 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
                             // chunks each when frames overlap (a pool's rays grow with the group's samples; measured at configs[3],
                             // 16 samples: 0.625 -> 0.607 ms with 4 096 items, but 0.74 -> 0.79 ms one frame at a time; configs[4]'s
                             // frame, 64 samples: 16 384 is best either way)
-                            ctx->wf_lane_items ? ctx->wf_lane_items : (ctx->n_slots > 1u ? std::min(16384u, 256u * group) : 16384u)};
+                            ctx->wf_lane_items ? ctx->wf_lane_items : (ctx->n_slots > 1u ? std::min(16384u, 256u * group) : 16384u),
+                            ctx->wf_packet_dense_rays};
         if (overlap) {   // the other streams start behind this frame's setup (and so behind the previous frame's resolve)
             RWR_HIP_CHECK(hipEventRecord(W.fork, stream));
             for (size_t q = 1; q < n_queues; q++) RWR_HIP_CHECK(hipStreamWaitEvent(W.streams[q], W.fork, 0));

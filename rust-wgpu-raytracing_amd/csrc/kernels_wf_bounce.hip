@@ -99,7 +99,7 @@ struct SortShared {
 template <uint32_t NT>
 RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, const WfBuffers &wf, PoolInfo *__restrict__ info,
                        uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list, uint32_t n_tiles,
-                       uint32_t sample_count, uint32_t min_fill, float packet_extent)
+                       uint32_t sample_count, uint32_t min_fill, float packet_extent, uint32_t dense_rays)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t n_masks = sample_count * 8u, n_slots = sample_count * kWfTilePixels;
@@ -119,8 +119,11 @@ RWR_DEV void sort_pool(SortShared &sh, uint16_t *s_bins, const uint32_t tile, co
         return;
     }
     const size_t pool_base = (size_t)tile * wf.group * kWfTilePixels;
-    bool packets = n_rays >= min_fill;
-    if (packets) {   // uniform: how far apart do the rays start?  (the first two samples' slots)
+    // (a pool of very many rays sorts into packets that are tight in DIRECTION whatever patch of surface they start from: a
+    // packet covers 128 / n_rays of the sphere)
+    const bool dense = dense_rays != 0u && n_rays >= dense_rays;
+    bool packets = dense || n_rays >= min_fill;
+    if (packets && !dense) {   // uniform: how far apart do the rays start?  (the first two samples' slots)
         constexpr int kPerThread = 1024 / (int)NT;
         float4 o[kPerThread];
         bool live_slot[kPerThread];
@@ -239,19 +242,19 @@ static_assert(kWfSortThreads >= kWfMaxGroup * 8u && kWfSortThreads >= 256u, "one
 template <bool LIST>
 __global__ void __launch_bounds__(kWfSortThreads)
 k_wf_sort(const WfBuffers wf, PoolInfo *__restrict__ info, uint32_t *__restrict__ counters, uint32_t *__restrict__ pool_list,
-          uint32_t n_tiles, uint32_t sample_count, uint32_t min_fill, float packet_extent)
+          uint32_t n_tiles, uint32_t sample_count, uint32_t min_fill, float packet_extent, uint32_t dense_rays)
 {
     __shared__ SortShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     uint16_t *s_bins = reinterpret_cast<uint16_t *>(s_dyn);   // direction bin of every slot (0xffff: no ray), then the sorted list: 2 x 2 B x sample_count x 512
     if (!LIST) {
-        sort_pool<kWfSortThreads>(sh, s_bins, blockIdx.x, wf, info, counters, pool_list, n_tiles, sample_count, min_fill, packet_extent);
+        sort_pool<kWfSortThreads>(sh, s_bins, blockIdx.x, wf, info, counters, pool_list, n_tiles, sample_count, min_fill, packet_extent, dense_rays);
         return;
     }
     const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)*wf.live_count);
     for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)wf.live_list[t]);
-        sort_pool<kWfSortThreads>(sh, s_bins, tile, wf, info, counters, pool_list, n_tiles, sample_count, min_fill, packet_extent);
+        sort_pool<kWfSortThreads>(sh, s_bins, tile, wf, info, counters, pool_list, n_tiles, sample_count, min_fill, packet_extent, dense_rays);
         __syncthreads();   // (the next pool reuses the LDS)
     }
 }
@@ -712,10 +715,10 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
     }
     if (wf.live_list)
         hipLaunchKernelGGL(k_wf_sort<true>, dim3(std::min(n_tiles, 2048u)), dim3(kWfSortThreads), sort_lds, s, wf, info, counters, pool_list, n_tiles,
-                           sample_count, packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);
+                           sample_count, packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent, bvh.packet_dense_rays);
     else
         hipLaunchKernelGGL(k_wf_sort<false>, dim3(n_tiles), dim3(kWfSortThreads), sort_lds, s, wf, info, counters, pool_list, n_tiles,
-                           sample_count, packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent);
+                           sample_count, packets ? packet_min_rays : 0xffffffffu, bvh.packet_extent, bvh.packet_dense_rays);
     const dim3 grid(std::min(kWfTraceGroups, n_tiles * kWfMaxSplit));
     const bool nmap = (fp.flags & RWR_FLAG_NORMAL_MAP) != 0;
     if (packets) {

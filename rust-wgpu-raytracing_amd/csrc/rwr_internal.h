@@ -246,6 +246,7 @@ struct BvhDevice {
     float packet_extent;   // pools whose ray origins span less than this are traced as packets (kernels_wf_bounce.hip)
     uint32_t min_packet_pools;  // fewer packet pools than this in a launch group: the per-lane kernel traces them
     uint32_t lane_items;        // work items the per-lane kernel's launch should have when pools are few (pool_split; tunable)
+    uint32_t packet_dense_rays; // a pool of at least this many rays is traced as packets however far apart its rays start (0: never)
 };
 
 struct FusedSetup;

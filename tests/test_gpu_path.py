@@ -184,12 +184,16 @@ def test_schedules_of_the_integrator_give_the_same_frame(rwr, orc, suzanne, scen
     params = rwr.make_params(spp=spp, max_bounces=1, seed=3, flags=rwr.FLAG_AUX_OUTPUTS)
     want = orc.render_path(cam_inv.view(orc.CAMERA_INV_DTYPE), orc.make_screen(w, h), orc.make_params(spp, 1, seed=3),
                            orc.make_spheres(), suzanne, instances=None if inst is None else inst.view(orc.INSTANCE_DTYPE))
-    keys = ("RWR_WF_ZSPLIT", "RWR_WF_OVERLAP", "RWR_WF_GROUP")
+    keys = ("RWR_WF_ZSPLIT", "RWR_WF_OVERLAP", "RWR_WF_GROUP", "RWR_WF_PACKET_RAYS", "RWR_WF_MIN_PACKET_POOLS")
     saved = {k: os.environ.get(k) for k in keys}
     frames = []
     try:
-        for zsplit, queues, group in (("1", "1", "32"), ("4", "1", "32"), ("3", "2", "2"), ("1", "2", "3"), ("0", "4", "1"), ("8", "3", "4")):
-            os.environ.update({"RWR_WF_ZSPLIT": zsplit, "RWR_WF_OVERLAP": queues, "RWR_WF_GROUP": group})
+        # (the last two: every pool of 40 / 400 rays or more traced as packets however far apart its rays start — the rule
+        # for pools of very many rays, with the threshold pulled down to these small frames' pools)
+        for zsplit, queues, group, dense in (("1", "1", "32", "0"), ("4", "1", "32", "0"), ("3", "2", "2", "0"), ("1", "2", "3", "0"),
+                                             ("0", "4", "1", "0"), ("8", "3", "4", "0"), ("1", "1", "32", "40"), ("4", "2", "4", "400")):
+            os.environ.update({"RWR_WF_ZSPLIT": zsplit, "RWR_WF_OVERLAP": queues, "RWR_WF_GROUP": group, "RWR_WF_PACKET_RAYS": dense,
+                               "RWR_WF_MIN_PACKET_POOLS": "0" if dense != "0" else "128"})
             with rwr.Context(0) as ctx:        # the tunables are read when the context is created
                 got = _gpu(rwr, ctx, suzanne, rwr.make_spheres(), cam_inv, w, h, params, instances=inst)
                 again = _gpu(rwr, ctx, suzanne, rwr.make_spheres(), cam_inv, w, h, params, instances=inst)   # (zsplit 0: now from the first frame's live count)
