@@ -139,7 +139,8 @@ struct rwr_context {
     uint32_t bvh_n_nodes = 0, bvh_depth = 0;
     float bvh_leaf_extent = 0.0f;
     float wf_packet_extent = 0.5f;   // x mean leaf extent; tunable: RWR_WF_PACKET_EXTENT
-    uint32_t wf_min_packet_pools = 128;   // tunable: RWR_WF_MIN_PACKET_POOLS
+    uint32_t wf_min_packet_pools = 64;    // tunable: RWR_WF_MIN_PACKET_POOLS (a quarter share of configs[4]'s frame has about 100 packet pools of 30 000 rays
+                                          // and is 5 % faster with them as packets, an eighth share has 50 and is 10 % faster per lane: tools/share_probe.py)
     uint32_t wf_lane_items = 0;           // tunable: RWR_WF_LANE_ITEMS (0: chosen per frame, see the BvhDevice of the wavefront path)
     uint32_t wf_packet_dense_rays = 16384;   // a pool of at least this many rays (32 samples of a full tile) is traced as packets
                                              // however far apart its rays start; tunable: RWR_WF_PACKET_RAYS (0: never).  Measured

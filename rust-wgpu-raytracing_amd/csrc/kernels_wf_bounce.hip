@@ -54,7 +54,7 @@ constexpr uint32_t kWfMaxSplit = 32;       // at most this many work items share
 constexpr uint32_t kWfWholePools = 1024;   // this many live pools keep the chip busy by themselves
 constexpr uint32_t kWfTargetItemsDense = 4096;
 constexpr uint32_t kWfTraceGroups = 2048;  // workgroups of a trace launch (persistent: they pull work items)
-// Fewer packet pools than `min_packet_pools` (default 128, BvhDevice) in a launch group: the per-lane kernel takes them
+// Fewer packet pools than `min_packet_pools` (default 64, BvhDevice) in a launch group: the per-lane kernel takes them
 // (a packet is one long chain of dependent scalar loads; a handful of them on an otherwise idle chip take longer
 // than everything else in the frame).
 // device counters of one launch group (one set per ray queue, WfBuffers::counters): pools of each class, work items handed out
