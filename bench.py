@@ -147,7 +147,8 @@ def main() -> int:
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--frames-in-flight", type=int, default=None,
-                    help="frame slots (targets, per-frame records, stream, gather buffers) the context alternates between; default 2 (3 with a gather)")
+                    help="frame slots (targets, per-frame records, stream, gather buffers) the context alternates between; default 2 for the "
+                         "reference frame, 3 with a gather and for the wavefront configurations")
     ap.add_argument("--skip-serial", action="store_true",
                     help="leave out the one-frame-at-a-time segment after the timed region (profiling runs: every frame of the "
                          "process then runs the same schedule)")
@@ -223,7 +224,9 @@ def main() -> int:
     # Three with a gather: pack -> exchange -> deal-out of a frame is a longer chain than its render, and the exchange's host cost
     # (one grouped RCCL call, 20 us) sits between the launches — measured on a one-rank rehearsal: 56.8 / 49.1 / 39.2 us per frame
     # with 1 / 2 / 3 slots (profiles/r03_bench_cfg2_force_dist*.json).
-    fif = args.frames_in_flight if args.frames_in_flight else (3 if use_dist else 2)
+    # Three for the wavefront configurations too (a frame there is a chain of a dozen launches with latency-bound ends: a third
+    # frame fills more of them — configs[2] 7.62 -> 7.48 ms, configs[4]'s frame 1.74 -> 1.69, configs[3] +-0, one box).
+    fif = args.frames_in_flight if args.frames_in_flight else (3 if (use_dist or not primary_only) else 2)
     ctx.set_frames_in_flight(fif)
 
     loop_keys = [dict(W=rwr.KEY_FORWARD, S=rwr.KEY_BACKWARD, A=rwr.KEY_LEFT, D=rwr.KEY_RIGHT)[k] for k in cfg.get("loop_keys", "")]

@@ -78,7 +78,7 @@ for cfg in CFGS:
         c = p[k]
         if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU", (0, 0))[0] > 0:
             lanes[k] = round(c["SQ_THREAD_CYCLES_VALU"][0] / c["SQ_ACTIVE_INST_VALU"][0], 1)
-    counters[cfg] = {"source": f"profiles/r03_pmc_{cfg}_summary.txt", "frames_in_flight": 2, "dominant_kernel": dominant,
+    counters[cfg] = {"source": f"profiles/r03_pmc_{cfg}_summary.txt", "frames_in_flight": 2 if cfg in ("cfg2", "cfg2b") else 3, "dominant_kernel": dominant,
                      **{k: round(v, 1) for k, v in tot.items()}, "traffic_bytes_per_step": traffic,
                      "valu_lanes_live_of_64": lanes or None, "kernels": detail}
 counters["_csrc_tree"] = graft.load_package().csrc_tree()   # bench.py flags its roofline block when the library has changed since
