@@ -142,6 +142,7 @@ struct rwr_context {
     uint32_t wf_min_packet_pools = 64;    // tunable: RWR_WF_MIN_PACKET_POOLS (a quarter share of configs[4]'s frame has about 100 packet pools of 30 000 rays
                                           // and is 5 % faster with them as packets, an eighth share has 50 and is 10 % faster per lane: tools/share_probe.py)
     uint32_t wf_lane_items = 0;           // tunable: RWR_WF_LANE_ITEMS (0: chosen per frame, see the BvhDevice of the wavefront path)
+    int32_t wf_wide_lane = -1;            // the per-lane trace kernel as 1 024-thread workgroups: -1 by itself (below), tunable: RWR_WF_WIDE_LANE=0/1
     uint32_t wf_packet_dense_rays = 16384;   // a pool of at least this many rays (32 samples of a full tile) is traced as packets
                                              // however far apart its rays start; tunable: RWR_WF_PACKET_RAYS (0: never).  Measured
                                              // (tools/packet_rays_sweep.sh): configs[4]'s frame, 64 samples per group, 2.11 -> 1.75
@@ -558,6 +559,7 @@ int rwr_ctx_create(int device_id, rwr_context **out_ctx)
     if (const char *e13 = std::getenv("RWR_WF_OVERLAP")) ctx->wf_queues = std::min(rwr_context::kWfMaxQueues, std::max(1u, (uint32_t)std::strtoul(e13, nullptr, 10)));
     if (const char *e12 = std::getenv("RWR_WF_ZSPLIT")) ctx->wf_z_split = (uint32_t)std::strtoul(e12, nullptr, 10);
     if (const char *e19 = std::getenv("RWR_WF_PACKET_RAYS")) ctx->wf_packet_dense_rays = (uint32_t)std::strtoul(e19, nullptr, 10);
+    if (const char *e20 = std::getenv("RWR_WF_WIDE_LANE")) ctx->wf_wide_lane = std::atoi(e20) != 0 ? 1 : 0;
     if (const char *e15 = std::getenv("RWR_WF_LANE_ITEMS")) ctx->wf_lane_items = std::max(1u, (uint32_t)std::strtoul(e15, nullptr, 10));
     if (const char *e10 = std::getenv("RWR_WF_MIN_PACKET_POOLS")) ctx->wf_min_packet_pools = (uint32_t)std::strtoul(e10, nullptr, 10);
     if (const char *e8 = std::getenv("RWR_WF_PACKET_EXTENT")) ctx->wf_packet_extent = (float)std::atof(e8);
@@ -1089,7 +1091,7 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
         RWR_HIP_CHECK(launch_primary_dormant(stream, fp, st, ctx->d_tris.ptr, ctx->d_shade.ptr, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront && ((rp.flags & RWR_FLAG_USE_BVH) || auto_bvh)) {
-        const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u, 0.0f, 0u, 0u, 0u};
+        const BvhDevice bvh_p{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u, 0.0f, 0u, 0u, 0u, 0u};
         RWR_HIP_CHECK(launch_primary_bvh(stream, fp, ctx->d_tris.ptr, ctx->d_shade.ptr, bvh_p, tex0, tg));
         ctx->last_spp = 0;
     } else if (!wavefront) {
@@ -1188,6 +1190,14 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
                                W.d_wave_total.ptr, group, tiles_x, ctx->d_wf_dbg.ptr,
                                rp.max_bounces ? W.d_live.ptr + h * 4u : nullptr, overlap ? 1u : 0u, live_list, live_count, tile_live};
         }
+        // The per-lane trace kernel as 1 024-thread workgroups that share ONE copy of the nodelets in LDS (kernels_wf_bounce.hip,
+        // WIDE; only for a BVH too large for a copy per 256-thread workgroup and small enough for one per CU), one work item per
+        // pool: when frames overlap and the frame before traced most of its pools per lane (a small mesh on an empty screen at few
+        // samples: configs[3] 0.604 -> 0.54 ms; one frame at a time it loses, 0.73 -> 0.81, and configs[4]'s frame, whose large
+        // pools are packets, loses 2 %: both keep the 256-thread kernel).  Same frame either way.
+        const uint32_t prev_packets = ctx->h_wf_live ? ctx->h_wf_live[0] : 0u, prev_lane = ctx->h_wf_live ? ctx->h_wf_live[1] : 0u;
+        const bool wide_lane = ctx->wf_wide_lane >= 0 ? ctx->wf_wide_lane != 0
+                                                       : (ctx->n_slots > 1u && prev_lane >= 128u && prev_lane >= 4u * prev_packets);
         const BvhDevice bvh{ctx->d_bvh_nodes.ptr, ctx->d_bvh_leaf_faces.ptr, ctx->bvh_n_nodes, 3u * ctx->bvh_depth + 2u,
                             ctx->wf_packet_extent * ctx->bvh_leaf_extent, ctx->wf_min_packet_pools,
                             // work items of the per-lane trace kernel when pools are few: one 256-ray chunk each for a context that
@@ -1195,8 +1205,8 @@ static int render_frame(rwr_context *ctx, const rwr_camera_inv_uniform *camera, 
                             // chunks each when frames overlap (a pool's rays grow with the group's samples; measured at configs[3],
                             // 16 samples: 0.625 -> 0.607 ms with 4 096 items, but 0.74 -> 0.79 ms one frame at a time; configs[4]'s
                             // frame, 64 samples: 16 384 is best either way)
-                            ctx->wf_lane_items ? ctx->wf_lane_items : (ctx->n_slots > 1u ? std::min(16384u, 256u * group) : 16384u),
-                            ctx->wf_packet_dense_rays};
+                            ctx->wf_lane_items ? ctx->wf_lane_items : (wide_lane ? 256u : ctx->n_slots > 1u ? std::min(16384u, 256u * group) : 16384u),
+                            ctx->wf_packet_dense_rays, wide_lane ? 1u : 0u};
         if (overlap) {   // the other streams start behind this frame's setup (and so behind the previous frame's resolve)
             RWR_HIP_CHECK(hipEventRecord(W.fork, stream));
             for (size_t q = 1; q < n_queues; q++) RWR_HIP_CHECK(hipStreamWaitEvent(W.streams[q], W.fork, 0));

@@ -285,7 +285,7 @@ RWR_DEV void flush_pool(TraceShared &sh, const FrameParams &p, const WfBuffers &
 {
     const uint32_t tile_x0 = (tile % wf.tiles_x) * kWfTileW, tile_y0 = p.row_begin + (tile / wf.tiles_x) * p.row_pitch;
     const size_t plane = (size_t)p.width * p.height;   // (planes 0..2: red, green, blue; plane 3 is the primary stage's alpha)
-    for (uint32_t q = threadIdx.x; q < kWfTilePixels; q += 256u) {
+    for (uint32_t q = threadIdx.x; q < kWfTilePixels; q += blockDim.x) {
         const uint32_t px = tile_x0 + (q & (kWfTileW - 1u)), py = tile_y0 + q / kWfTileW;
         const unsigned long long sr = sh.acc[q * 3u], sg = sh.acc[q * 3u + 1u], sb = sh.acc[q * 3u + 2u];
         if ((sr | sg | sb) != 0ull && px < p.width && py < p.row_end) {
@@ -336,8 +336,11 @@ RWR_DEV bool next_item(TraceShared &sh, const PoolInfo *__restrict__ info, uint3
 #else
 #define RWR_LANE_BOUNDS __launch_bounds__(256)
 #endif
-template <bool NODES_IN_LDS, bool NMAP, bool STACK16>
-__global__ void RWR_LANE_BOUNDS
+// WIDE: a workgroup of 1 024 threads that shares ONE copy of the nodelets in LDS (a BVH too large for four 256-thread
+// workgroups per CU to hold a copy each — 508 nodes = 65 KB at configs[3] — but small enough for one per CU): every node fetch
+// of the traversal then comes from LDS instead of through the vector memory pipe, 64 different 16-byte pieces per load.
+template <bool NODES_IN_LDS, bool NMAP, bool STACK16, bool WIDE = false>
+__global__ void __launch_bounds__(WIDE ? 1024 : 256)
 k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const ShadeRec *__restrict__ shade,
                 const BvhDevice bvh, const float4 *__restrict__ tex, const WfBuffers wf, const PoolInfo *__restrict__ info,
                 uint32_t *__restrict__ counters, const uint32_t *__restrict__ pool_list, uint32_t n_tiles)
@@ -359,10 +362,10 @@ k_wf_trace_lane(const FrameParams p, const TriRecord *__restrict__ tris, const S
         if (NODES_IN_LDS && !staged) {
             const float4 *src = reinterpret_cast<const float4 *>(bvh.nodes);
             float4 *dst = reinterpret_cast<float4 *>(s_nodes);
-            for (uint32_t i = tid; i < bvh.n_nodes * 8u; i += 256u) dst[i] = src[i];
+            for (uint32_t i = tid; i < bvh.n_nodes * 8u; i += blockDim.x) dst[i] = src[i];
             staged = true;
         }
-        for (uint32_t i = tid; i < kWfTilePixels * 3u; i += 256u) sh.acc[i] = 0ull;
+        for (uint32_t i = tid; i < kWfTilePixels * 3u; i += blockDim.x) sh.acc[i] = 0ull;
         if (tid == 0u) sh.next_packet = 0u;
         __syncthreads();
         const size_t pool_base = (size_t)tile * wf.group * kWfTilePixels;
@@ -733,7 +736,23 @@ hipError_t launch_wf_bounce(hipStream_t s, const FrameParams &fp, const TriRecor
 #define RWR_LANE_LAUNCH2(L, BYTES) \
     if (nmap) { if (stack16) RWR_LANE_LAUNCH(L, true, true, BYTES); else RWR_LANE_LAUNCH(L, true, false, BYTES); } \
     else { if (stack16) RWR_LANE_LAUNCH(L, false, true, BYTES); else RWR_LANE_LAUNCH(L, false, false, BYTES); }
+    const size_t fixed_wide = 4u * fixed, wide_bytes = node_bytes + fixed_wide;
     if (node_bytes + fixed <= 28u * 1024u) { RWR_LANE_LAUNCH2(true, node_bytes + fixed) }
+    else if (bvh.wide_lane && !nmap && stack16 && wide_bytes + 14u * 1024u <= 160u * 1024u) {
+        // a BVH too large for a copy per 256-thread workgroup, small enough for one copy per CU: 1 024-thread workgroups
+        static std::atomic<uint64_t> wide_raised_on{0};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(wide_raised_on.load(std::memory_order_acquire) & bit)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_trace_lane<true, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 146 * 1024);
+            if (e != hipSuccess) return e;
+            wide_raised_on.fetch_or(bit, std::memory_order_release);
+        }
+        hipLaunchKernelGGL((k_wf_trace_lane<true, false, true, true>), dim3(std::min(512u, n_tiles * kWfMaxSplit)), dim3(1024), wide_bytes, s, fp, tris, shade, bvh, tex,
+                           wf, info, counters, pool_list, n_tiles);
+    }
     else { RWR_LANE_LAUNCH2(false, fixed) }
 #undef RWR_LANE_LAUNCH2
 #undef RWR_LANE_LAUNCH

@@ -247,6 +247,7 @@ struct BvhDevice {
     uint32_t min_packet_pools;  // fewer packet pools than this in a launch group: the per-lane kernel traces them
     uint32_t lane_items;        // work items the per-lane kernel's launch should have when pools are few (pool_split; tunable)
     uint32_t packet_dense_rays; // a pool of at least this many rays is traced as packets however far apart its rays start (0: never)
+    uint32_t wide_lane;         // the per-lane trace kernel may run as 1 024-thread workgroups sharing one LDS copy of the nodelets
 };
 
 struct FusedSetup;
