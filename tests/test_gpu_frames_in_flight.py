@@ -160,3 +160,36 @@ def test_one_launch_per_frame_gives_the_same_frames(rwr, orc, suzanne, monkeypat
                 asm[rows] = part[rows]
             assert np.array_equal(asm, full), fif
         ctx.synchronize()
+
+
+@pytest.mark.gpu
+def test_wide_per_lane_kernel_is_picked_and_gives_the_same_frame(rwr, suzanne, monkeypatch):
+    """configs[3]'s scene at full size with frames in flight: from the second frame on the context traces the sparse pools with
+    the per-lane kernel's WIDE form (1 024-thread workgroups sharing one LDS copy of the 508 nodelets, one work item per pool) —
+    picked by itself from the previous frame's pool counts.  Same bytes as the single-slot frame and as the frame with the
+    WIDE form switched off."""
+    w, h = 3840, 2160
+    cam = rwr.camera_build_inv_uniform(rwr.make_camera(eye=(0, 0, 12), aspect=w / h))
+    params = rwr.make_params(spp=6, max_bounces=1, seed=9)
+    frames = {}
+    for label, env, fif in (("single", None, 1), ("auto", None, 2), ("off", "0", 2), ("forced", "1", 1)):
+        if env is None:
+            monkeypatch.delenv("RWR_WF_WIDE_LANE", raising=False)
+        else:
+            monkeypatch.setenv("RWR_WF_WIDE_LANE", env)
+        with rwr.Context(0) as ctx:
+            ctx.upload_model(suzanne)
+            ctx.set_spheres(rwr.make_spheres())
+            ctx.set_instances(rwr.make_instance_grid(4, 3.0))
+            ctx.resize(w, h)
+            ctx.set_frames_in_flight(fif)
+            for _ in range(4):          # (the pool counts arrive a frame late: the later frames take the WIDE form)
+                ctx.render(cam, params)
+            out = ctx.readback()
+            frames[label] = (out["color"].copy(), out["depth"].copy(), ctx.last_render_stats())
+    ref = frames["single"]
+    assert ref[0].any() and ref[2][1] > 100000          # a real frame with bounce rays
+    for label in ("auto", "off", "forced"):
+        assert np.array_equal(frames[label][0], ref[0]), label
+        assert np.array_equal(frames[label][1].view(np.uint32), ref[1].view(np.uint32)), label
+        assert frames[label][2] == ref[2], label
